@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REAL REFERENCE.
+
+Run only in the build container, where /root/reference exists (it does not travel):
+
+    cd /tmp && python -B /root/repo/tests/golden/make_golden.py
+
+This script contains no reference source.  It imports the reference's modules from
+/root/reference (with `sys.modules` stubs for the absent `torchvision`, whose only use - the
+DeformConv2d class - is dead code), loads seeded synthetic weights made by
+``rtm3d_amd.weights.synth_state_dict`` into the reference ``Model``, runs it on synthetic inputs
+and stores inputs + outputs as small .npz files.  tests/test_oracle_golden.py then checks the CPU
+oracle (oracle/) against these files, and the `-m gpu` tests check the HIP path against them.
+"""
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+tv = types.ModuleType('torchvision')
+tvo = types.ModuleType('torchvision.ops')
+tvm = types.ModuleType('torchvision.models')
+tvo.DeformConv2d = type('DeformConv2d', (), {})
+tv.ops, tv.models = tvo, tvm
+sys.modules.update({'torchvision': tv, 'torchvision.ops': tvo, 'torchvision.models': tvm})
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from types import SimpleNamespace as NS  # noqa: E402
+from scipy.optimize import minimize  # noqa: E402
+
+from models.nets import dla, resnet  # noqa: E402  (reference)
+from models.model import Model  # noqa: E402       (reference)
+from utils import model_utils as ref_mu  # noqa: E402 (reference)
+
+from rtm3d_amd import weights  # noqa: E402
+
+torch.set_num_threads(8)
+DIM_REF = [[1.52607842, 1.62858147, 3.88396124], [1.76067766, 0.6602296, 0.84220464],
+           [1.73712792, 0.59677122, 1.76338868]]          # models/configs/rtm3d_dla34_kitti.yaml:18-27
+REF_LOC = [0, -0.5, 20]                                    # detect.py:74
+KFNS = {'DLA-34': ['level2', 'level3', 'level4', 'level5'], 'RESNET-18': ['layer1', 'layer2', 'layer3', 'layer4']}
+
+
+def make_cfg(backbone, thresh=0.4, topk=100):
+    return NS(MODEL=NS(BACKBONE=backbone, DOWN_SAMPLE=4., OUT_CHANNELS=256, KFNs=KFNS[backbone], HEADER_NUM_CONV=2),
+              DATASET=NS(OBJs=['Car', 'Pedestrian', 'Cyclist'], VERTEX_OFFSET_INFER=[0.75, 0.57]),
+              DETECTOR=NS(SCORE_THRESH=thresh, TOPK_CANDIDATES=topk))
+
+
+def ref_model(backbone, sd, thresh=0.4, topk=100):
+    cfg = make_cfg(backbone, thresh, topk)
+    bb = dla.create_model(cfg) if 'DLA' in backbone else resnet.get_pose_net(backbone.split('-')[-1], cfg)
+    m = Model(cfg, bb).eval()
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m
+
+
+def dets_to_arrays(dets, prefix, out):
+    clses, scores, mprojs, verts, boxes = dets
+    B = len(clses)
+    n = np.array([0 if c is None else len(c) for c in clses], np.int32)
+    out[prefix + 'n'] = n
+    for b in range(B):
+        if clses[b] is None:
+            continue
+        out['%scls_%d' % (prefix, b)] = clses[b].numpy().astype(np.int64)
+        out['%sscore_%d' % (prefix, b)] = scores[b].numpy()
+        out['%smproj_%d' % (prefix, b)] = mprojs[b].numpy()
+        out['%sverts_%d' % (prefix, b)] = verts[b].numpy()
+        out['%sbbox_%d' % (prefix, b)] = boxes[b].numpy()
+
+
+def assert_tie_free(main_kf_logits, topk):
+    """CPU topk tie order is implementation-defined; make sure fixtures never depend on it."""
+    for i in range(main_kf_logits.shape[0]):
+        hm = ref_mu.nms_hm(torch.sigmoid(main_kf_logits[i:i + 1].clone()), 3).reshape(-1)
+        s, _ = torch.topk(hm, topk + 1)
+        s = s[s > 0]
+        assert len(torch.unique(s)) == len(s), 'tie among the top-(k+1) scores of image %d' % i
+
+
+def gen_e2e():
+    # (backbone, seed, heat_bias, B, H, W, tag)
+    cases = [('DLA-34', 1, -6.0, 2, 128, 256, 'small'), ('RESNET-18', 1, -5.0, 2, 128, 256, 'small'),
+             ('DLA-34', 1, -6.0, 1, 384, 1280, 'full'), ('RESNET-18', 1, -5.0, 1, 384, 1280, 'full')]
+    for bb, seed, hb, B, H, W, tag in cases:
+        sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
+        m = ref_model(bb, sd)
+        x = weights.synth_images(B, H, W, seed=1234)
+        with torch.no_grad():
+            dets, logits = m(x)
+        assert_tie_free(logits[0], 100)
+        out = {'backbone': bb, 'seed': seed, 'heat_bias': hb, 'style': 'trained', 'shape': np.array([B, H, W]),
+               'img_seed': 1234,
+               # guards against drift of the numpy bit-stream that regenerates weights/images on another box
+               'w_probe': sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1].copy(),
+               'x_probe': x[0, :, :2, :8].numpy().copy()}
+        if tag == 'small':
+            for i, name in enumerate(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset']):
+                out['logits_' + name] = logits[i].numpy()
+        else:
+            out['logits_main_kf'] = logits[0].numpy()
+            for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
+                out['logits_%s_s4' % name] = logits[i][:, :, ::4, ::4].numpy().copy()
+            # full-resolution values of the regression heads at the detected key points
+            for b in range(B):
+                if dets[0][b] is None:
+                    continue
+                mp = dets[2][b] / 4.0
+                xi, yi = mp[:, 0].floor().long(), mp[:, 1].floor().long()
+                out['offs_at_det_%d' % b] = logits[1][b][:, yi, xi].numpy()
+                out['moff_at_det_%d' % b] = logits[2][b][:, yi, xi].numpy()
+        dets_to_arrays(dets, 'det_', out)
+        # 3D decode of image 0 through the reference function
+        K = weights.synth_intrinsics()
+        if dets[0][0] is not None:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                pl = ref_mu.optim_decode_bbox3d(dets[0][0].numpy(), dets[3][0].numpy(), K.copy(), DIM_REF, list(REF_LOC))
+            out['d3_class'] = np.array(pl.get_field('class'), np.int64)
+            out['d3_Ry'] = np.asarray(pl.get_field('Ry'), np.float64)
+            out['d3_dimension'] = np.asarray(pl.get_field('dimension'), np.float64)
+            out['d3_location'] = np.asarray(pl.get_field('location'), np.float64)
+        out['K'] = K
+        name = 'e2e_%s_%s.npz' % (bb.lower().replace('-', ''), tag)
+        np.savez_compressed(os.path.join(HERE, name), **out)
+        print(name, 'ndet', out['det_n'], 'logit absmax', [float(l.abs().max()) for l in logits])
+
+
+def gen_decode2d():
+    """Model.inference (models/model.py:29-75) on synthetic logits; weights are irrelevant here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('golden_cases', os.path.join(HERE, 'cases.py'))
+    gc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gc)
+    DECODE2D_CASES, decode2d_inputs = gc.DECODE2D_CASES, gc.decode2d_inputs
+    m = ref_model('RESNET-18', None)
+    out = {}
+    for name in DECODE2D_CASES:
+        th, tk, arrs = decode2d_inputs(name)
+        lg = [torch.from_numpy(a) for a in arrs]
+        m.config.DETECTOR.SCORE_THRESH, m.config.DETECTOR.TOPK_CANDIDATES = th, tk
+        if name != 'plateau':
+            assert_tie_free(lg[0], tk)
+        with torch.no_grad():
+            dets = m.inference([l.clone() for l in lg])
+        out[name + '_probe'] = np.concatenate([a.reshape(-1)[:16] for a in arrs])
+        dets_to_arrays(dets, name + '_det_', out)
+        print('decode2d', name, out[name + '_det_n'])
+    np.savez_compressed(os.path.join(HERE, 'decode2d_cases.npz'), **out)
+
+
+def gen_decode3d():
+    """optim_decode_bbox3d (utils/model_utils.py:264-312) on synthetic key points; the raw optimiser
+    state (x, fun, nit) is recorded by calling SciPy with the reference's own aimFun/jac."""
+    from oracle.decode3d_ref import project_box, COR
+    rng = np.random.Generator(np.random.PCG64(11))
+    K = weights.synth_intrinsics()
+    clses, uvs, noise_tag = [], [], []
+    for noise in (0.0, 0.01, 0.3, 2.0):
+        for _ in range(16):
+            cls = int(rng.integers(0, 3))
+            dim = np.array(DIM_REF[cls]) * rng.uniform(0.8, 1.25, 3)
+            loc = np.array([rng.uniform(-12, 12), rng.uniform(0.5, 1.6), rng.uniform(6, 55)])
+            ry = rng.uniform(-np.pi, np.pi)
+            uv = project_box(dim, loc, ry, K) + noise * rng.standard_normal((8, 2))
+            clses.append(cls); uvs.append(uv.astype(np.float32)); noise_tag.append(noise)
+    clses = np.array(clses, np.int64)
+    uvs = np.stack(uvs)                      # fp32, as v_projs_regress arrives from the model (detect.py:72)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pl = ref_mu.optim_decode_bbox3d(clses, uvs, K.copy(), DIM_REF, list(REF_LOC))
+        raw = {'x': [], 'fun': [], 'nit': [], 'nfev': []}
+        options = {'disp': None, 'maxcor': 10, 'ftol': 2.220446049250313e-09, 'gtol': 1e-05, 'eps': 1e-08,
+                   'maxfun': 15000, 'maxiter': 15000, 'iprint': -1, 'maxls': 20, 'finite_diff_rel_step': None}
+        K33 = K.reshape(3, 3)
+        for cls, UV in zip(clses, uvs):
+            dim = DIM_REF[cls]
+            X0 = np.array([0, 1] + [dim[2], dim[0], dim[1]] + REF_LOC)
+            res = minimize(ref_mu.aimFun(*(COR, K33, UV.T)), X0, method='L-BFGS-B',
+                           jac=ref_mu.jac(*(COR, K33, UV.T)), options=options)
+            raw['x'].append(res.x); raw['fun'].append(res.fun); raw['nit'].append(res.nit); raw['nfev'].append(res.nfev)
+    out = {'clses': clses, 'uv': uvs, 'K': K, 'dim_ref': np.array(DIM_REF), 'ref_loc': np.array(REF_LOC, np.float64),
+           'noise': np.array(noise_tag),
+           'out_class': np.array(pl.get_field('class'), np.int64), 'out_Ry': np.asarray(pl.get_field('Ry')),
+           'out_dimension': np.asarray(pl.get_field('dimension')), 'out_location': np.asarray(pl.get_field('location')),
+           'out_K': np.asarray(pl.get_field('K')),
+           'raw_x': np.array(raw['x']), 'raw_fun': np.array(raw['fun']), 'raw_nit': np.array(raw['nit']),
+           'raw_nfev': np.array(raw['nfev'])}
+    np.savez_compressed(os.path.join(HERE, 'decode3d_cases.npz'), **out)
+    print('decode3d: %d objects, kept %d, nit %d..%d' % (len(clses), len(out['out_class']), out['raw_nit'].min(), out['raw_nit'].max()))
+    # empty case behaviour (:307-311)
+    pl = ref_mu.optim_decode_bbox3d(np.zeros((0,), np.int64), np.zeros((0, 8, 2), np.float32), K.copy(), DIM_REF, list(REF_LOC))
+    assert pl.get_field('dimension').shape == (0, 3) and pl.get_field('K').shape == (0, 9)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['e2e', 'decode2d', 'decode3d']
+    if 'decode3d' in which:
+        gen_decode3d()
+    if 'decode2d' in which:
+        gen_decode2d()
+    if 'e2e' in which:
+        gen_e2e()

@@ -1,0 +1,81 @@
+"""CPU: pin the oracle (oracle/) against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  Bit-exact for the forward/2D decode (same PyTorch CPU kernels),
+1e-9 for the SciPy-driven 3D decode."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rtm3d_ref, decode3d_ref
+from rtm3d_amd import weights
+from tests.golden.cases import DECODE2D_CASES, decode2d_inputs
+from tests.util import load_golden, dets_from_golden, to_np, canon_dets
+
+E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
+
+
+@pytest.mark.parametrize('fname', E2E)
+def test_oracle_forward_matches_reference(fname):
+    g = load_golden(fname)
+    bb = str(g['backbone'])
+    B, H, W = [int(v) for v in g['shape']]
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']))
+    x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
+    # the seeded generators must reproduce the tensors the reference was run on
+    np.testing.assert_array_equal(sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1], g['w_probe'])
+    np.testing.assert_array_equal(x[0, :, :2, :8].numpy(), g['x_probe'])
+    torch.set_num_threads(8)
+    dets, logits = rtm3d_ref.model_forward(x, sd, bb)
+    # conv results may differ in the last bits with the thread count / oneDNN blocking of the host
+    np.testing.assert_allclose(logits[0].numpy(), g['logits_main_kf'], rtol=0, atol=2e-5)
+    if 'logits_offset_fr_main' in g:
+        for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
+            np.testing.assert_allclose(logits[i].numpy(), g['logits_' + name], rtol=0, atol=2e-5)
+    else:
+        for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
+            np.testing.assert_allclose(logits[i][:, :, ::4, ::4].numpy(), g['logits_%s_s4' % name], rtol=0, atol=2e-5)
+    n = g['det_n']
+    for b in range(B):
+        if n[b] == 0:
+            assert dets[0][b] is None
+            continue
+        ref = dets_from_golden(g, 'det_', b)
+        np.testing.assert_array_equal(dets[0][b].numpy(), ref[0])           # classes: exact
+        np.testing.assert_allclose(dets[1][b].numpy(), ref[1], atol=1e-5)
+        for k in (2, 3, 4):
+            np.testing.assert_allclose(dets[k][b].numpy(), ref[k], atol=2e-4)
+
+
+@pytest.mark.parametrize('name', DECODE2D_CASES)
+def test_oracle_decode2d_bit_exact(name):
+    g = load_golden('decode2d_cases.npz')
+    th, tk, arrs = decode2d_inputs(name)
+    np.testing.assert_array_equal(np.concatenate([a.reshape(-1)[:16] for a in arrs]), g[name + '_probe'])
+    dets = rtm3d_ref.inference([torch.from_numpy(a) for a in arrs], th, tk, 4.0)
+    n = g[name + '_det_n']
+    for b in range(len(n)):
+        if n[b] == 0:
+            assert dets[0][b] is None
+            continue
+        got = [to_np(d[b]) for d in dets]
+        ref = dets_from_golden(g, name + '_det_', b)
+        if name == 'plateau':     # tie order of torch.topk is implementation-defined: compare canonically
+            got, ref = canon_dets(*got), canon_dets(*ref)
+        for a, r in zip(got, ref):
+            np.testing.assert_array_equal(a, r)
+
+
+def test_oracle_decode3d_matches_reference():
+    g = load_golden('decode3d_cases.npz')
+    res, raw = decode3d_ref.optim_decode_bbox3d(g['clses'], g['uv'], g['K'], g['dim_ref'].tolist(),
+                                                g['ref_loc'].tolist(), return_raw=True)
+    np.testing.assert_array_equal(np.array(res['class']), g['out_class'])
+    np.testing.assert_array_equal(raw['nit'], g['raw_nit'])
+    np.testing.assert_allclose(raw['x'], g['raw_x'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(raw['fun'], g['raw_fun'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res['Ry'], g['out_Ry'], atol=1e-9)
+    np.testing.assert_allclose(res['dimension'], g['out_dimension'], atol=1e-9)
+    np.testing.assert_allclose(res['location'], g['out_location'], atol=1e-9)
+    np.testing.assert_array_equal(res['K'], g['out_K'])
+    # empty input (utils/model_utils.py:307-311)
+    e = decode3d_ref.optim_decode_bbox3d(np.zeros((0,), np.int64), np.zeros((0, 8, 2)), g['K'], g['dim_ref'].tolist(), [0, -0.5, 20])
+    assert e['dimension'].shape == (0, 3) and e['K'].shape == (0, 9) and e['class'] == []
