@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Throughput of the RTM3D inference hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch already resident in HBM:
+backbone + neck + heads (HIP MFMA/direct convs) -> 2D decode (sigmoid/NMS/top-k/gather) ->
+3D decode (fp64 L-BFGS-B per object) [-> at N>1: one RCCL all-gather of the detection records].
+Workload = BASELINE.json configs[2]: rtm3d_dla34_kitti, bs=32 per GPU, 384x1280, fp16 storage /
+fp32 accumulate, seeded synthetic weights ("trained"-style) and images.  Weak scaling: every rank
+processes its own 32-image shard (configs[3] = 8 x 32).
+
+Prints ONE JSON line (rank 0) with the driver's keys plus `roofline` (dominant kernel, timed live
+with hipEvents on the launch stream) and `cpu_baseline` (the CPU oracle = PyTorch-CPU fp32
+restatement of the reference + SciPy L-BFGS-B, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+# (backbone) -> (weight seed, heat-map bias) giving a sparse, realistic number of detections/image
+SYNTH = {'DLA-34': (1, -6.0), 'RESNET-18': (1, -5.0)}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--backbone', default='DLA-34')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=1280)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
+    return ap.parse_args()
+
+
+def cpu_baseline(backbone, sd, H, W, n_images, cfg):
+    """The oracle timed on this host: forward + 2D decode (PyTorch-CPU fp32) and the SciPy 3D decode."""
+    from oracle import rtm3d_ref, decode3d_ref
+    from rtm3d_amd import weights
+    threads = torch.get_num_threads()
+    x = weights.synth_images(n_images, H, W, seed=1234)
+    K = weights.synth_intrinsics()
+    rtm3d_ref.model_forward(x[:1], sd, backbone)            # warm-up (thread pool, oneDNN primitives)
+    t0 = time.time()
+    nobj = 0
+    for i in range(n_images):
+        dets, _ = rtm3d_ref.model_forward(x[i:i + 1], sd, backbone, cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES)
+        if dets[0][0] is not None:
+            nobj += len(dets[0][0])
+            decode3d_ref.optim_decode_bbox3d(dets[0][0].numpy(), dets[3][0].numpy(), K, cfg.DETECTOR.dim_ref, [0, -0.5, 20])
+    dt = time.time() - t0
+    return {'value': n_images / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d images bs=1 %s %dx%d fp32 PyTorch-CPU oracle forward + 2D decode + SciPy L-BFGS-B 3D decode of %d objects, %.1f s'
+                      % (n_images, backbone, H, W, nobj, dt)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+    if args.gpus != world and rank == 0:
+        print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+
+    import rtm3d_amd
+    from rtm3d_amd import weights, distributed as rdist
+    bb = args.backbone
+    B, H, W = args.batch, args.height, args.width
+    cfg = rtm3d_amd.kitti_config(bb)
+    seed, hb = SYNTH.get(bb, (1, -6.0))
+    sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
+    model = rtm3d_amd.create_model(cfg).to(dev).eval()
+    model.load_state_dict(sd)
+    # this rank's shard of the global synthetic batch (image b uses seed 1234+b: rank independent)
+    x = weights.synth_images(B, H, W, seed=1234, first=rank * B).to(dev)
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
+    topk = int(cfg.DETECTOR.TOPK_CANDIDATES)
+
+    def step():
+        det, boxes, _ = model.detect3d(x, K)
+        rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, topk, boxes)
+        return rdist.all_gather_records(rec), det
+
+    # ---- warm-up (also records the plan) and choice of the dominant kernel for the live probe
+    rec, det = step()
+    torch.cuda.synchronize(dev)
+    plan = model._plan_for(B, H, W, dev)
+    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in (3, 16, 2, 2)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
+    info = plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
+    dom = max(range(len(info)), key=lambda i: info[i]['ms'])
+    plan.probe_set(dom)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    plan.probe_set(dom)                         # reset the probe ring: only timed steps are averaged
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec, det = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dom_ms, dom_n = plan.probe_read()
+    n_det = det.n.sum().item()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        total_images = B * world * args.steps
+        flops_fwd = plan.plan.total_flops()
+        d = info[dom]
+        roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (d['kernel'], d['name']),
+                'achieved': d['flops'] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
+                'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': (d['flops'] / (dom_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS) if dom_ms > 0 else None,
+                'traffic': None, 'launch_ms': dom_ms, 'launches_timed': dom_n,
+                'flops_per_launch': d['flops'],
+                'whole_forward_frac': flops_fwd / (sum(i['ms'] for i in info) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
+        out = {'metric': 'images_per_sec', 'value': total_images / dt, 'unit': 'images/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16', 'data': 'synthetic',
+               'config': {'workload': 'rtm3d_%s_kitti forward+decode2d+decode3d, bs=%d/GPU, %dx%d, fp16 storage fp32 accumulate'
+                                      % (bb.lower().replace('-', ''), B, H, W),
+                          'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                          'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9},
+               'roofline': roof}
+        if args.per_op:
+            tot = sum(i['ms'] for i in info)
+            print('%-28s %-22s %9s %9s %8s' % ('op', 'kernel', 'ms', 'TFLOP/s', 'GB/s'), file=sys.stderr)
+            for i in info:
+                print('%-28s %-22s %9.3f %9.1f %8.0f' % (i['name'][:28], i['kernel'], i['ms'], i['flops'] / i['ms'] / 1e9 if i['ms'] else 0,
+                                                         i['bytes'] / i['ms'] / 1e6 if i['ms'] else 0), file=sys.stderr)
+            print('forward total %.3f ms (per-op event timing)' % tot, file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, args.cpu_images, cfg)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,157 @@
+/*
+ * rtm3d_hip.h - C ABI of librtm3d_hip.so, the MI355X (gfx950) implementation of the RTM3D
+ * inference hot path.
+ *
+ * The reference (hitfeelee/rtm3d) has no native code and no FFI: its "operator API" for this path
+ * is the Python surface  Model.forward / Model.inference / optim_decode_bbox3d.  Each entry point
+ * below names the reference interface (file:line under /root/reference) whose arithmetic it
+ * replaces; the Python binding a maintainer would add is shown in INTEGRATION.md and is what
+ * rtm3d_amd/_lib.py does with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()), every h_* pointer is HOST memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are stream-ordered
+ *     and never synchronise unless stated;
+ *   - every function returns 0 on success, non-zero on error; rtm3d_last_error() then returns a
+ *     thread-local description.  "No detections" is not an error (n_out[b] == 0), mirroring the
+ *     `None` list entries of models/model.py:33-44;
+ *   - a context is not re-entrant: one caller thread / one stream at a time, one context per
+ *     process-GPU (the reference is single-threaded per process, train_multi_gpu.py:243).
+ */
+#ifndef RTM3D_HIP_H
+#define RTM3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTM3D_ABI_VERSION 1
+#define RTM3D_MAX_GROUPS 4
+#define RTM3D_MAX_TAPS 9
+
+typedef struct rtm3d_ctx rtm3d_ctx;
+
+const char* rtm3d_last_error(void);
+int rtm3d_abi_version(void);
+
+/* ------------------------------------------------------------------ context / plan building
+ * A context owns the activation workspace (padded NHWC fp16 tensors), the packed + BN-folded
+ * weights and an ordered list of kernel launches ("the plan") for ONE network at ONE input shape.
+ * The host (Python, rtm3d_amd/plan.py) records the plan once; rtm3d_forward replays it.
+ * Replaces: the nn.Module graph walked by Model.forward, models/model.py:20-27.                  */
+int rtm3d_ctx_create(int device, rtm3d_ctx** out);
+void rtm3d_ctx_destroy(rtm3d_ctx* ctx);
+
+/* Activation tensor: [B][H+2*pad][W+2*pad][C] fp16, zero border (written once at creation and
+ * never touched by kernels, which is what implements the convolutions' zero padding).           */
+int rtm3d_tensor_create(rtm3d_ctx* ctx, int B, int H, int W, int C, int pad, int* id);
+/* Debug / parity helpers: copy channels [c0, c0+C) of the interior to/from fp32 NCHW host memory
+ * (synchronous).                                                                                 */
+int rtm3d_tensor_download(rtm3d_ctx* ctx, int id, int c0, int C, float* h_nchw);
+int rtm3d_tensor_upload(rtm3d_ctx* ctx, int id, int c0, int C, const float* h_nchw);
+
+/* Device blob (packed weights / folded biases).  Copies `bytes` from host; returns blob id.      */
+int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t bytes, int* id);
+
+/* First layer: direct KxK convolution of the caller's fp32 NCHW image (Cin = 3) + folded BN +
+ * ReLU, written as padded NHWC fp16.  Replaces models/nets/dla.py:259-268 (7x7 s1 3->16) and
+ * models/nets/resnet.py:124-126 (7x7 s2 3->64).
+ * weights blob: fp32 [ky][kx][cin][cout]; bias blob: fp32 [cout].                                */
+int rtm3d_op_stem(rtm3d_ctx* ctx, int out_tensor, int ksize, int stride, int pad, int cout,
+                  int w_blob, int bias_blob);
+
+/* Generic convolution descriptor (one launch; `groups` independent sub-problems on grid.z).
+ * Covers conv KxK (any stride / dilation), 1x1 over channel slices of wider tensors (the DLA root
+ * "concat" never materialises: producers write slices), grouped head convs, and the four
+ * sub-pixel phases of ConvTranspose2d(k4,s2,p1) (models/nets/module.py:7-15).
+ * Iteration domain: m in [0, B*Hm*Wm) -> (n, y, x).
+ *   input  pixel (n, y*in_stride + tap_dy[g][t], x*in_stride + tap_dx[g][t])   (unpadded coords)
+ *   output pixel (n, y*out_scale + out_oy[g],    x*out_scale + out_ox[g])
+ * Epilogue: + bias[cout] (BN folded) [+ residual at the output pixel] [ReLU] -> fp16 NHWC,
+ * or (out_nchw_f32 != 0) fp32 NCHW into the caller buffer given to rtm3d_forward.                */
+typedef struct rtm3d_conv_desc {
+    int in_tensor, out_tensor, res_tensor; /* res_tensor < 0: none; out_tensor < 0 with out_nchw_f32 */
+    int Hm, Wm;                            /* iteration domain per image */
+    int in_stride, out_scale;
+    int cin, cout;                         /* per group (cout = real output channels) */
+    int groups, ntaps;
+    int in_coff[RTM3D_MAX_GROUPS], out_coff[RTM3D_MAX_GROUPS], res_coff[RTM3D_MAX_GROUPS];
+    int out_oy[RTM3D_MAX_GROUPS], out_ox[RTM3D_MAX_GROUPS];
+    int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
+    int relu;
+    int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
+    int kernel;                            /* 0 = MFMA implicit GEMM (cin % 64 == 0), 1 = direct dot2 (small cin) */
+    int bn_tile;                           /* MFMA: cout tile the weights were packed for (16/32/64/128) */
+    int out_nchw_f32;                      /* 0, or 1..4 = index+1 into rtm3d_forward's out_logits[] */
+    int out_H, out_W;                      /* only for out_nchw_f32 */
+} rtm3d_conv_desc;
+int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
+
+/* Max pooling k x k / stride / pad over channel slice, NHWC fp16 (models/nets/dla.py:170-172,
+ * models/nets/resnet.py:128).  Inputs are post-ReLU (>= 0) so the zero border equals -inf padding. */
+int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff,
+                     int channels, int ksize, int stride, int pad);
+
+/* z_out = z + sum_i u_i * softmax_{H*W}(u_i)  per (image, channel)
+ * (models/nets/keypoint_fpn_fusion.py:60-69).  n_u <= 3.                                         */
+int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_u, const int* u_tensors);
+
+/* Replay the plan.  d_in: fp32 NCHW (B,3,H,W) normalised image batch (detect.py:53);
+ * d_out_logits[4]: fp32 NCHW (B,3|16|2|2,H/4,W/4) = pred_logits of models/model.py:22-27.        */
+int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]);
+
+/* Per-op timing of one replay with hipEvents (synchronous; for profiling/bench):
+ * h_ms[i] = elapsed ms of op i; returns number of ops through *n_ops (h_ms may be NULL).          */
+int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
+                        float* h_ms, int cap, int* n_ops);
+/* Algorithmic work of op i: flops (2*MAC) and minimum bytes moved; name is a static string.       */
+int rtm3d_op_info(rtm3d_ctx* ctx, int i, double* flops, double* bytes, const char** name);
+
+/* Live probe for roofline accounting: record a hipEvent pair around op `op_index` on the caller's
+ * stream in every rtm3d_forward (op_index < 0 disables); rtm3d_probe_read synchronises on the
+ * recorded events and returns the average duration of the (up to 64) most recent launches.          */
+int rtm3d_probe_set(rtm3d_ctx* ctx, int op_index);
+int rtm3d_probe_read(rtm3d_ctx* ctx, double* avg_ms, int* count);
+
+/* ------------------------------------------------------------------ 2D decode
+ * sigmoid -> 3x3 equality NMS -> top-k -> threshold -> gather/regress 8 vertices + 2D box.
+ * Replaces Model.inference, models/model.py:29-98,117-132 and nms_hm, utils/model_utils.py:17-26.
+ * Inputs fp32 NCHW logits.  Outputs (all device, caller-owned), image b at row b:
+ *   d_n[B] int32 count; d_cls[B*topk] int64; d_score[B*topk]; d_mproj[B*topk*2];
+ *   d_verts[B*topk*16] (8 x (x,y)); d_bbox[B*topk*4] (x1,y1,x2,y2); rows >= n are untouched.
+ * Order within an image: score descending, ties by ascending flat index (class-major).
+ * d_workspace: at least rtm3d_decode2d_workspace_bytes(B, ncls, H, W) bytes.                      */
+size_t rtm3d_decode2d_workspace_bytes(int B, int ncls, int H, int W);
+int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_fr_main,
+                   const float* d_main_offset, int B, int ncls, int H, int W, float score_thresh,
+                   int topk, float down_sample, void* d_workspace, int32_t* d_n, int64_t* d_cls,
+                   float* d_score, float* d_mproj, float* d_verts, float* d_bbox);
+
+/* ------------------------------------------------------------------ 3D decode
+ * Per object: minimise the 8-corner reprojection error over [sin,cos,l,h,w,X,Y,Z] with an fp64
+ * L-BFGS-B (m=10, factr=1e7, pgtol=1e-5, maxls=20, unbounded) started at
+ * [0,1,l_ref,h_ref,w_ref,ref_loc].  Replaces optim_decode_bbox3d, utils/model_utils.py:264-312
+ * (objective :155-177, gradient :206-234) and scipy.optimize.minimize(method='L-BFGS-B').
+ *   d_cls[N] int64, d_verts[N*16] fp32, d_K[N*9] fp64 (row-major 3x3 per object),
+ *   d_dim_ref[ncls*3] fp64 (h,w,l), d_ref_loc[3] fp64.
+ * Outputs: d_x[N*8] fp64 final iterate, d_fun[N] fp64, d_nit[N] int32, d_status[N] int32
+ * (0 converged, 1 max iterations, 2 abnormal line search).  The caller applies `fun < 0.1`.       */
+int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                   const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
+                   double* d_fun, int32_t* d_nit, int32_t* d_status);
+
+/* Same solver over the fixed-size slots written by rtm3d_decode2d, without a host round trip:
+ * slot i = (image i / topk, rank i % topk) is solved iff rank < d_n[image]; other slots get
+ * status -1 and are otherwise untouched.  d_K_per_image[B*9].  Outputs have B*topk rows.          */
+int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
+                         const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
+                         const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTM3D_HIP_H */

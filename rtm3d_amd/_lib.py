@@ -1,0 +1,93 @@
+"""ctypes binding of librtm3d_hip.so (C ABI in include/rtm3d_hip.h).
+
+The product path has no CPU fallback: if the library is missing or cannot be loaded, every
+entry point raises ``RuntimeError`` telling the user to run ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
+ABI_VERSION = 1
+MAX_GROUPS, MAX_TAPS = 4, 9
+
+c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
+c_double = ctypes.c_double
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of struct rtm3d_conv_desc."""
+    _fields_ = [
+        ('in_tensor', c_int), ('out_tensor', c_int), ('res_tensor', c_int),
+        ('Hm', c_int), ('Wm', c_int),
+        ('in_stride', c_int), ('out_scale', c_int),
+        ('cin', c_int), ('cout', c_int),
+        ('groups', c_int), ('ntaps', c_int),
+        ('in_coff', c_int * MAX_GROUPS), ('out_coff', c_int * MAX_GROUPS), ('res_coff', c_int * MAX_GROUPS),
+        ('out_oy', c_int * MAX_GROUPS), ('out_ox', c_int * MAX_GROUPS),
+        ('tap_dy', (c_int * MAX_TAPS) * MAX_GROUPS), ('tap_dx', (c_int * MAX_TAPS) * MAX_GROUPS),
+        ('relu', c_int),
+        ('w_blob', c_int), ('bias_blob', c_int),
+        ('kernel', c_int), ('bn_tile', c_int),
+        ('out_nchw_f32', c_int), ('out_H', c_int), ('out_W', c_int),
+    ]
+
+
+# name -> (restype, argtypes); also the list of symbols include/rtm3d_hip.h declares
+SIGNATURES = {
+    'rtm3d_last_error': (ctypes.c_char_p, []),
+    'rtm3d_abi_version': (c_int, []),
+    'rtm3d_ctx_create': (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    'rtm3d_ctx_destroy': (None, [c_void_p]),
+    'rtm3d_tensor_create': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_tensor_download': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rtm3d_tensor_upload': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rtm3d_blob_create': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int)]),
+    'rtm3d_op_stem': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
+    'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_forward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
+    'rtm3d_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_op_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_char_p)]),
+    'rtm3d_probe_set': (c_int, [c_void_p, c_int]),
+    'rtm3d_probe_read': (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
+    'rtm3d_decode2d_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'rtm3d_decode2d': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rtm3d_decode3d': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    'rtm3d_decode3d_slots': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('rtm3d_amd: HIP library %s is missing - build it with '
+                           '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C rtm3d_amd/csrc`). '
+                           'There is no CPU fallback.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError('rtm3d_amd: cannot load %s: %s (ROCm runtime present? there is no CPU fallback)' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = library/ABI mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rtm3d_abi_version() != ABI_VERSION:
+        raise RuntimeError('rtm3d_amd: ABI version mismatch (library %d, binding %d)' % (lib.rtm3d_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().rtm3d_last_error()
+        raise RuntimeError('rtm3d_hip %s failed: %s' % (what, msg.decode() if msg else 'unknown error'))

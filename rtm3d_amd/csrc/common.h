@@ -1,0 +1,83 @@
+// Shared declarations between the runtime (runtime.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RT_MAX_GROUPS 4
+#define RT_MAX_TAPS 9
+
+// Geometry of one padded NHWC fp16 activation tensor as the kernels see it.
+struct TensorView {
+    f16* base;          // element [n=0][yp=0][xp=0][c=0] of the padded buffer
+    int Hp, Wp, C, P;   // padded height/width, channel pitch, border width
+};
+
+struct ConvGroupArgs {
+    int in_coff, out_coff, res_coff;
+    int out_oy, out_ox;
+    uint32_t w_off;          // element offset of this group's packed weights
+    int bias_off;            // element offset into bias
+    int tap_off[RT_MAX_TAPS];  // (dy*in_Wp + dx)*in_C, elements (may be negative)
+};
+
+struct ConvKArgs {
+    const f16* in;
+    const f16* wgt;
+    const float* bias;
+    const f16* res;
+    void* out;
+    int M, HmWm, Wm;
+    int in_Hp, in_Wp, in_C, in_stride, in_P;
+    int out_Hp, out_Wp, out_C, out_scale, out_P;
+    int res_Hp, res_Wp, res_C, res_P;
+    int cin, cout, ksteps, cpt;   // cpt = 64-channel chunks per tap (MFMA path)
+    int ntaps;
+    int relu, MT, NT;
+    int out_H, out_W;             // NCHW fp32 epilogue only
+    ConvGroupArgs g[RT_MAX_GROUPS];
+};
+
+struct StemKArgs {
+    const float* in;      // fp32 NCHW (B,3,H,W)
+    const float* wgt;     // fp32 [ky][kx][ci][co]
+    const float* bias;    // fp32 [co]
+    f16* out;
+    int B, H, W, Ho, Wo, stride, pad;
+    int out_Hp, out_Wp, out_C, out_P;
+};
+
+struct PoolKArgs {
+    const f16* in; f16* out;
+    int B, Ho, Wo, C8;            // C8 = channels/8
+    int in_Hp, in_Wp, in_C, in_P, in_coff;
+    int out_Hp, out_Wp, out_C, out_P, out_coff;
+    int ksize, stride, pad;
+};
+
+struct SoftmaxKArgs {
+    const f16* z_in; f16* z_out;
+    const f16* u[3];
+    int n_u;
+    int B, H, W, C;                // C == 256
+    int z_Hp, z_Wp, z_C, z_P;      // z_out geometry
+    int zi_Hp, zi_Wp, zi_C, zi_P;  // z_in geometry
+    int u_Hp[3], u_Wp[3], u_C[3], u_P[3];
+    float* partial;                // [n_u][B][chunks][C][2] (max, sumexp)
+    int chunks, rows_per_chunk;
+};
+
+// kernel launchers (each returns hipGetLastError())
+hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
+hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStream_t s);
+bool conv_direct_supported(int cin, int cout, int ntaps);
+hipError_t launch_stem(const StemKArgs& a, int ksize, int cout, hipStream_t s);
+bool stem_supported(int ksize, int cout);
+hipError_t launch_maxpool(const PoolKArgs& a, hipStream_t s);
+hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s);

@@ -1,0 +1,203 @@
+// 2D decode: sigmoid -> 3x3 equality NMS -> top-k -> threshold -> key-point regression.
+// Replaces Model.inference / _obtain_main_proj2d / _obtain_offset_fr_main
+// (models/model.py:29-98,117-132) and nms_hm (utils/model_utils.py:17-26).
+//
+// One 1024-thread workgroup per image:
+//   A  sigmoid of the K*H*W heat-map logits -> workspace (L2 resident, 368 KB at 3x96x320)
+//   B  3x3 max with -inf border, keep s == max (all members of a plateau survive, like the
+//      reference), compact survivors with s > thresh as unique 64-bit keys
+//      (score bits << 32 | ~flat_index) -> candidate list
+//   C  exact radix select (8 passes x 8 bits) of the top-k-th key, gather keys >= it, rank them
+//      => order: score descending, ties by ascending flat (class-major) index
+//   D  one lane per detection: class/y/x from the flat index, 16-channel offset gather, sub-pixel
+//      sigmoid, vertices and 2D box in the reference's fp32 operation order.
+//
+// Bit-exactness: the fp32 sigmoid reproduces what PyTorch-CPU computes: the vectorised path is
+// Sleef's expf_u10 polynomial (fma form) followed by an IEEE divide; elements that fall in the
+// scalar tail of ATen's vectorised loop (last n % 32 elements of a < 32768-element tensor on an
+// AVX-512 host) use a correctly rounded expf instead.  Verified against torch.sigmoid on 16M values.
+#include "common.h"
+#include "../../include/rtm3d_hip.h"
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float ldexp2kf(float d, int e) {
+    const float a = __int_as_float(((e >> 1) + 127) << 23);
+    const float b = __int_as_float(((e - (e >> 1)) + 127) << 23);
+    return d * a * b;
+}
+
+__device__ __forceinline__ float expf_sleef_u10(float d) {
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
+    const int q = (int)rintf(d * R_LN2f);
+    float s = __fmaf_rn((float)q, -L2Uf, d);
+    s = __fmaf_rn((float)q, -L2Lf, s);
+    float u = 0.000198527617612853646278381f;
+    u = __fmaf_rn(u, s, 0.00139304355252534151077271f);
+    u = __fmaf_rn(u, s, 0.00833336077630519866943359f);
+    u = __fmaf_rn(u, s, 0.0416664853692054748535156f);
+    u = __fmaf_rn(u, s, 0.166666671633720397949219f);
+    u = __fmaf_rn(u, s, 0.5f);
+    u = 1.0f + __fmaf_rn(s * s, u, s);
+    u = ldexp2kf(u, q);
+    if (d < -104.0f) u = 0.0f;
+    if (d > 100.0f) u = INFINITY;
+    return u;
+}
+
+// vector == true : ATen Vectorized<float> path;  false : scalar tail (1/(1+std::exp(-x)))
+__device__ __forceinline__ float sigmoid_aten(float x, bool vector) {
+    float e;
+    if (vector) e = expf_sleef_u10(0.0f - x);
+    else e = (float)exp((double)(-x));
+    return __fdiv_rn(1.0f, 1.0f + e);
+}
+
+#define D2_THREADS 1024
+#define D2_MAXK 256
+#define ATEN_GRAIN 32768
+#define ATEN_VSTEP 32
+
+__global__ __launch_bounds__(D2_THREADS) void decode2d_kernel(
+    const float* __restrict__ main_kf, const float* __restrict__ offs, const float* __restrict__ moff,
+    int ncls, int H, int W, float thresh, int topk, float down,
+    float* __restrict__ ws_sig, unsigned long long* __restrict__ ws_cand,
+    int32_t* __restrict__ out_n, int64_t* __restrict__ out_cls, float* __restrict__ out_score,
+    float* __restrict__ out_mproj, float* __restrict__ out_verts, float* __restrict__ out_bbox) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int HW = H * W, total = ncls * HW;
+    const float* hm = main_kf + (size_t)b * total;
+    float* sig = ws_sig + (size_t)b * total;
+    unsigned long long* cand = ws_cand + (size_t)b * total;
+
+    __shared__ int hist[256];
+    __shared__ unsigned long long sel[D2_MAXK];
+    __shared__ int s_n, s_nsel, s_bin, s_cum;
+
+    if (tid == 0) { s_n = 0; s_nsel = 0; }
+    // ---- A: sigmoid
+    const int vec_end = (total < ATEN_GRAIN) ? (total / ATEN_VSTEP) * ATEN_VSTEP : total;
+    for (int i = tid; i < total; i += D2_THREADS) sig[i] = sigmoid_aten(hm[i], i < vec_end);
+    __syncthreads();
+    // ---- B: NMS + compaction
+    for (int i = tid; i < total; i += D2_THREADS) {
+        const int c = i / HW, r = i - c * HW, y = r / W, x = r - y * W;
+        const float* pl = sig + c * HW;
+        const float s = pl[r];
+        float mx = s;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                mx = fmaxf(mx, pl[yy * W + xx]);
+            }
+        }
+        if (mx == s && s > thresh) {
+            const int pos = atomicAdd(&s_n, 1);
+            cand[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    // ---- C: exact top-k by radix select on the unique 64-bit keys
+    unsigned long long T = 0ull;
+    if (n > topk) {
+        unsigned long long prefix = 0ull, mask = 0ull;
+        int remaining = topk;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += D2_THREADS) {
+                const unsigned long long k = cand[i];
+                if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, bin = 255;
+                for (; bin > 0; --bin) {
+                    if (cum + hist[bin] >= remaining) break;
+                    cum += hist[bin];
+                }
+                s_bin = bin; s_cum = cum;
+            }
+            __syncthreads();
+            remaining -= s_cum;
+            prefix |= (unsigned long long)s_bin << shift;
+            mask |= 0xFFull << shift;
+            __syncthreads();
+        }
+        T = prefix;
+    }
+    for (int i = tid; i < n; i += D2_THREADS) {
+        const unsigned long long k = cand[i];
+        if (k >= T) {
+            const int pos = atomicAdd(&s_nsel, 1);
+            if (pos < D2_MAXK) sel[pos] = k;
+        }
+    }
+    __syncthreads();
+    const int nsel = min(s_nsel, topk);
+    if (tid == 0) out_n[b] = nsel;
+    // ---- D: rank + gather (one lane per detection)
+    if (tid < nsel) {
+        const unsigned long long key = sel[tid];
+        int rank = 0;
+        for (int jx = 0; jx < nsel; ++jx) rank += (sel[jx] > key) ? 1 : 0;
+        const float score = __uint_as_float((unsigned)(key >> 32));
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        const int c = idx / HW, r = idx - c * HW, y = r / W, x = r - y * W;
+        // sub-pixel offset: sigmoid_ over the contiguous (2, N) gather result (models/model.py:48)
+        const int n2 = 2 * nsel;
+        const int vend = (n2 / ATEN_VSTEP) * ATEN_VSTEP;
+        const float* mo = moff + (size_t)b * 2 * HW;
+        const float sx = sigmoid_aten(mo[r], rank < vend);
+        const float sy = sigmoid_aten(mo[HW + r], (nsel + rank) < vend);
+        const float xf = (float)x + sx, yf = (float)y + sy;
+        const size_t row = (size_t)b * topk + rank;
+        out_cls[row] = (int64_t)c;
+        out_score[row] = score;
+        out_mproj[row * 2 + 0] = down * xf;
+        out_mproj[row * 2 + 1] = down * yf;
+        const float* of = offs + (size_t)b * 16 * HW + r;
+        float minx = INFINITY, miny = INFINITY, maxx = -INFINITY, maxy = -INFINITY;
+        for (int k = 0; k < 8; ++k) {
+            const float vx = down * (of[(size_t)(2 * k) * HW] + xf);
+            const float vy = down * (of[(size_t)(2 * k + 1) * HW] + yf);
+            out_verts[row * 16 + 2 * k] = vx;
+            out_verts[row * 16 + 2 * k + 1] = vy;
+            minx = fminf(minx, vx); miny = fminf(miny, vy);
+            maxx = fmaxf(maxx, vx); maxy = fmaxf(maxy, vy);
+        }
+        out_bbox[row * 4 + 0] = minx; out_bbox[row * 4 + 1] = miny;
+        out_bbox[row * 4 + 2] = maxx; out_bbox[row * 4 + 3] = maxy;
+    }
+}
+
+extern void rt_set_error(const char* fmt, ...);
+
+extern "C" size_t rtm3d_decode2d_workspace_bytes(int B, int ncls, int H, int W) {
+    return (size_t)B * ncls * H * W * (sizeof(float) + sizeof(unsigned long long)) + 256;
+}
+
+extern "C" int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_fr_main,
+                              const float* d_main_offset, int B, int ncls, int H, int W, float score_thresh,
+                              int topk, float down_sample, void* d_workspace, int32_t* d_n, int64_t* d_cls,
+                              float* d_score, float* d_mproj, float* d_verts, float* d_bbox) {
+    if (B <= 0 || ncls <= 0 || H <= 0 || W <= 0) { rt_set_error("decode2d: bad shape"); return 1; }
+    if (topk < 1 || topk > D2_MAXK) { rt_set_error("decode2d: topk must be in [1,%d]", D2_MAXK); return 1; }
+    if (!d_workspace || !d_main_kf || !d_offset_fr_main || !d_main_offset) { rt_set_error("decode2d: null pointer"); return 1; }
+    const size_t total = (size_t)B * ncls * H * W;
+    // candidate keys first (8-byte aligned), then the sigmoid plane
+    unsigned long long* cand = (unsigned long long*)(((uintptr_t)d_workspace + 7) & ~(uintptr_t)7);
+    float* sig = (float*)(cand + total);
+    hipLaunchKernelGGL(decode2d_kernel, dim3(B), dim3(D2_THREADS), 0, (hipStream_t)stream, d_main_kf, d_offset_fr_main,
+                       d_main_offset, ncls, H, W, score_thresh, topk, down_sample, sig, cand, d_n, d_cls, d_score,
+                       d_mproj, d_verts, d_bbox);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode2d launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}

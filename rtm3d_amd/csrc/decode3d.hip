@@ -1,0 +1,73 @@
+// 3D box decode on device: one lane per detected object runs the fp64 L-BFGS-B of lbfgsb.h.
+// Replaces optim_decode_bbox3d (utils/model_utils.py:264-312) + scipy L-BFGS-B.
+// The work is latency-bound fp64 (a few hundred kFLOP per object, <= topk objects per image), so the
+// kernel only needs enough lanes in flight: 64-lane workgroups, objects spread over the CUs.
+#include "common.h"
+#include "lbfgsb.h"
+#include "../../include/rtm3d_hip.h"
+
+// slot mode (n_per_image != nullptr): object i lives in slot (image = i / topk, rank = i % topk) of
+// the decode2d outputs, is valid iff rank < n_per_image[image], and uses K[image].
+__global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __restrict__ cls,
+                                                      const float* __restrict__ verts, const double* __restrict__ K,
+                                                      const double* __restrict__ dim_ref, int ncls,
+                                                      const double* __restrict__ ref_loc, double* __restrict__ x_out,
+                                                      double* __restrict__ f_out, int32_t* __restrict__ nit,
+                                                      int32_t* __restrict__ status,
+                                                      const int32_t* __restrict__ n_per_image, int topk) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= N) return;
+    int ki = i;
+    if (n_per_image) {
+        ki = i / topk;
+        if (i - ki * topk >= n_per_image[ki]) { status[i] = -1; return; }
+    }
+    LbProblem p;
+    p.k00 = K[ki * 9 + 0]; p.k02 = K[ki * 9 + 2]; p.k11 = K[ki * 9 + 4]; p.k12 = K[ki * 9 + 5];
+    for (int j = 0; j < 16; ++j) p.uv[j] = (double)verts[(size_t)i * 16 + j];
+    int c = (int)cls[i];
+    c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+    const double* dim = dim_ref + c * 3;            // (h, w, l)  -> x0 = [0, 1, l, h, w, ref_loc]
+    double x[8] = {0.0, 1.0, dim[2], dim[0], dim[1], ref_loc[0], ref_loc[1], ref_loc[2]};
+    LbWork w;
+    double f;
+    int it;
+    const int st = lb_minimize(&p, x, &f, &it, &w, 15000, 15000);
+    for (int j = 0; j < 8; ++j) x_out[(size_t)i * 8 + j] = x[j];
+    f_out[i] = f;
+    nit[i] = it;
+    status[i] = st;
+}
+
+extern void rt_set_error(const char* fmt, ...);
+
+extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                              const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
+                              double* d_fun, int32_t* d_nit, int32_t* d_status) {
+    if (N < 0 || ncls <= 0) { rt_set_error("decode3d: bad sizes"); return 1; }
+    if (N == 0) return 0;
+    if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
+        rt_set_error("decode3d: null pointer"); return 1;
+    }
+    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+                       d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode3d launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
+                                    const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
+                                    const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit,
+                                    int32_t* d_status) {
+    if (B <= 0 || topk <= 0 || ncls <= 0) { rt_set_error("decode3d_slots: bad sizes"); return 1; }
+    if (!d_n || !d_cls || !d_verts || !d_K_per_image || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
+        rt_set_error("decode3d_slots: null pointer"); return 1;
+    }
+    const int N = B * topk;
+    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+                       d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode3d_slots launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}

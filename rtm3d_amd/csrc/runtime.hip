@@ -1,0 +1,395 @@
+// Runtime of librtm3d_hip.so: context (activation workspace + packed weights + launch plan) and
+// the C ABI declared in include/rtm3d_hip.h.  The plan is recorded once by the host
+// (rtm3d_amd/plan.py) and replayed by rtm3d_forward on the caller's HIP stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "../../include/rtm3d_hip.h"
+
+static thread_local char g_err[512] = "";
+void rt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define RT_FAIL(...) do { rt_set_error(__VA_ARGS__); return 1; } while (0)
+#define RT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rt_set_error("%s: %s", #expr, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Tensor {
+    int B, H, W, C, P, Hp, Wp;
+    f16* alloc;     // allocation start (guard band in front)
+    f16* base;      // padded element [0][0][0][0]
+    size_t elems;   // padded elements (without guards)
+};
+
+enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_DIRECT, OP_MAXPOOL, OP_SOFTMAX };
+
+struct Op {
+    OpKind kind;
+    std::string name;
+    double flops, bytes;
+    ConvKArgs conv; int groups, bn_tile, epi_nchw, out_slot, ksize;
+    StemKArgs stem; int stem_cout;
+    PoolKArgs pool;
+    SoftmaxKArgs sm;
+};
+
+struct rtm3d_ctx {
+    int device;
+    std::vector<Tensor> tensors;
+    std::vector<void*> blobs;
+    std::vector<size_t> blob_bytes;
+    std::vector<Op> ops;
+    std::vector<void*> extra;   // other device allocations (softmax partials)
+    // live probe: hipEvent pairs around one op of every replay (bench.py roofline)
+    int probe_op = -1;
+    std::vector<hipEvent_t> probe_ev;   // 2 * PROBE_RING events
+    int probe_count = 0;
+};
+static const int PROBE_RING = 64;
+
+extern "C" const char* rtm3d_last_error(void) { return g_err; }
+extern "C" int rtm3d_abi_version(void) { return RTM3D_ABI_VERSION; }
+
+extern "C" int rtm3d_ctx_create(int device, rtm3d_ctx** out) {
+    if (!out) RT_FAIL("ctx_create: null out");
+    RT_HIP(hipSetDevice(device));
+    rtm3d_ctx* c = new rtm3d_ctx();
+    c->device = device;
+    *out = c;
+    return 0;
+}
+
+extern "C" void rtm3d_ctx_destroy(rtm3d_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& t : ctx->tensors) (void)hipFree(t.alloc);
+    for (auto p : ctx->blobs) (void)hipFree(p);
+    for (auto p : ctx->extra) (void)hipFree(p);
+    for (auto e : ctx->probe_ev) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+static const size_t GUARD = 4096;   // halves of slack on both sides of every activation buffer
+
+extern "C" int rtm3d_tensor_create(rtm3d_ctx* ctx, int B, int H, int W, int C, int pad, int* id) {
+    if (!ctx || !id) RT_FAIL("tensor_create: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || (C % 8) != 0) RT_FAIL("tensor_create: bad shape B=%d H=%d W=%d C=%d pad=%d (C must be a multiple of 8)", B, H, W, C, pad);
+    Tensor t;
+    t.B = B; t.H = H; t.W = W; t.C = C; t.P = pad; t.Hp = H + 2 * pad; t.Wp = W + 2 * pad;
+    t.elems = (size_t)B * t.Hp * t.Wp * C;
+    if (t.elems >= ((size_t)1 << 32) - 2 * GUARD) RT_FAIL("tensor_create: %zu elements exceed the 32-bit offset range of the kernels", t.elems);
+    const size_t bytes = (t.elems + 2 * GUARD) * sizeof(f16);
+    RT_HIP(hipMalloc((void**)&t.alloc, bytes));
+    RT_HIP(hipMemset(t.alloc, 0, bytes));
+    t.base = t.alloc + GUARD;
+    ctx->tensors.push_back(t);
+    *id = (int)ctx->tensors.size() - 1;
+    return 0;
+}
+
+static Tensor* get_tensor(rtm3d_ctx* ctx, int id) {
+    if (id < 0 || id >= (int)ctx->tensors.size()) return nullptr;
+    return &ctx->tensors[id];
+}
+
+extern "C" int rtm3d_tensor_download(rtm3d_ctx* ctx, int id, int c0, int C, float* h_nchw) {
+    Tensor* t = ctx ? get_tensor(ctx, id) : nullptr;
+    if (!t || !h_nchw || c0 < 0 || C <= 0 || c0 + C > t->C) RT_FAIL("tensor_download: bad arguments");
+    std::vector<f16> host(t->elems);
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(host.data(), t->base, t->elems * sizeof(f16), hipMemcpyDeviceToHost));
+    for (int n = 0; n < t->B; ++n)
+        for (int c = 0; c < C; ++c)
+            for (int y = 0; y < t->H; ++y)
+                for (int x = 0; x < t->W; ++x)
+                    h_nchw[(((size_t)n * C + c) * t->H + y) * t->W + x] =
+                        (float)host[(((size_t)n * t->Hp + y + t->P) * t->Wp + x + t->P) * t->C + c0 + c];
+    return 0;
+}
+
+extern "C" int rtm3d_tensor_upload(rtm3d_ctx* ctx, int id, int c0, int C, const float* h_nchw) {
+    Tensor* t = ctx ? get_tensor(ctx, id) : nullptr;
+    if (!t || !h_nchw || c0 < 0 || C <= 0 || c0 + C > t->C) RT_FAIL("tensor_upload: bad arguments");
+    std::vector<f16> host(t->elems);
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(host.data(), t->base, t->elems * sizeof(f16), hipMemcpyDeviceToHost));
+    for (int n = 0; n < t->B; ++n)
+        for (int c = 0; c < C; ++c)
+            for (int y = 0; y < t->H; ++y)
+                for (int x = 0; x < t->W; ++x)
+                    host[(((size_t)n * t->Hp + y + t->P) * t->Wp + x + t->P) * t->C + c0 + c] =
+                        (f16)h_nchw[(((size_t)n * C + c) * t->H + y) * t->W + x];
+    RT_HIP(hipMemcpy(t->base, host.data(), t->elems * sizeof(f16), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t bytes, int* id) {
+    if (!ctx || !h_data || !id || bytes == 0) RT_FAIL("blob_create: bad arguments");
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes + 256));
+    RT_HIP(hipMemset(p, 0, bytes + 256));
+    RT_HIP(hipMemcpy(p, h_data, bytes, hipMemcpyHostToDevice));
+    ctx->blobs.push_back(p);
+    ctx->blob_bytes.push_back(bytes);
+    *id = (int)ctx->blobs.size() - 1;
+    return 0;
+}
+
+static void* get_blob(rtm3d_ctx* ctx, int id, size_t* bytes) {
+    if (id < 0 || id >= (int)ctx->blobs.size()) return nullptr;
+    if (bytes) *bytes = ctx->blob_bytes[id];
+    return ctx->blobs[id];
+}
+
+extern "C" int rtm3d_op_stem(rtm3d_ctx* ctx, int out_tensor, int ksize, int stride, int pad, int cout,
+                             int w_blob, int bias_blob) {
+    Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    if (!o) RT_FAIL("op_stem: bad output tensor");
+    if (!stem_supported(ksize, cout) || o->C != cout) RT_FAIL("op_stem: unsupported ksize=%d cout=%d (tensor C=%d)", ksize, cout, o->C);
+    size_t wb = 0, bb = 0;
+    const float* w = (const float*)get_blob(ctx, w_blob, &wb);
+    const float* b = (const float*)get_blob(ctx, bias_blob, &bb);
+    if (!w || !b || wb != (size_t)ksize * ksize * 3 * cout * 4 || bb != (size_t)cout * 4) RT_FAIL("op_stem: weight/bias blob size mismatch");
+    Op op;
+    op.kind = OP_STEM; op.name = "stem_conv";
+    StemKArgs& a = op.stem;
+    a.in = nullptr; a.wgt = w; a.bias = b; a.out = o->base;
+    a.B = o->B; a.Ho = o->H; a.Wo = o->W; a.stride = stride; a.pad = pad;
+    a.H = o->H * stride; a.W = o->W * stride;
+    a.out_Hp = o->Hp; a.out_Wp = o->Wp; a.out_C = o->C; a.out_P = o->P;
+    op.stem_cout = cout; op.ksize = ksize;
+    op.flops = 2.0 * o->B * o->H * o->W * (double)ksize * ksize * 3 * cout;
+    op.bytes = (double)o->B * (3.0 * a.H * a.W * 4 + (double)o->H * o->W * cout * 2);
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
+    if (!ctx || !d) RT_FAIL("op_conv: null argument");
+    Tensor* in = get_tensor(ctx, d->in_tensor);
+    Tensor* out = d->out_nchw_f32 ? nullptr : get_tensor(ctx, d->out_tensor);
+    Tensor* res = d->res_tensor >= 0 ? get_tensor(ctx, d->res_tensor) : nullptr;
+    if (!in) RT_FAIL("op_conv: bad input tensor %d", d->in_tensor);
+    if (!d->out_nchw_f32 && !out) RT_FAIL("op_conv: bad output tensor %d", d->out_tensor);
+    if (d->res_tensor >= 0 && !res) RT_FAIL("op_conv: bad residual tensor %d", d->res_tensor);
+    if (d->groups < 1 || d->groups > RT_MAX_GROUPS || d->ntaps < 1 || d->ntaps > RT_MAX_TAPS) RT_FAIL("op_conv: groups/ntaps out of range");
+    if (d->out_nchw_f32 < 0 || d->out_nchw_f32 > 4) RT_FAIL("op_conv: out_nchw_f32 out of range");
+    size_t wbytes = 0, bbytes = 0;
+    const f16* w = (const f16*)get_blob(ctx, d->w_blob, &wbytes);
+    const float* bias = (const float*)get_blob(ctx, d->bias_blob, &bbytes);
+    if (!w || !bias) RT_FAIL("op_conv: bad weight/bias blob");
+
+    Op op;
+    ConvKArgs& a = op.conv;
+    memset(&a, 0, sizeof(a));
+    a.in = in->base; a.wgt = w; a.bias = bias; a.res = res ? res->base : nullptr; a.out = out ? (void*)out->base : nullptr;
+    a.HmWm = d->Hm * d->Wm; a.Wm = d->Wm; a.M = in->B * a.HmWm;
+    a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_stride = d->in_stride; a.in_P = in->P;
+    a.out_scale = d->out_scale;
+    if (out) { a.out_Hp = out->Hp; a.out_Wp = out->Wp; a.out_C = out->C; a.out_P = out->P; }
+    else { a.out_C = d->cout * d->groups; a.out_H = d->out_H; a.out_W = d->out_W; }
+    if (res) { a.res_Hp = res->Hp; a.res_Wp = res->Wp; a.res_C = res->C; a.res_P = res->P; }
+    a.cin = d->cin; a.cout = d->cout; a.ntaps = d->ntaps; a.relu = d->relu;
+    // bounds: every tap of every iteration pixel must stay inside the padded input
+    for (int g = 0; g < d->groups; ++g) {
+        for (int t = 0; t < d->ntaps; ++t) {
+            const int dy = d->tap_dy[g][t], dx = d->tap_dx[g][t];
+            const int ylo = dy, yhi = (d->Hm - 1) * d->in_stride + dy, xlo = dx, xhi = (d->Wm - 1) * d->in_stride + dx;
+            if (ylo < -in->P || xlo < -in->P || yhi >= in->H + in->P || xhi >= in->W + in->P)
+                RT_FAIL("op_conv: tap (%d,%d) leaves the padded input (H=%d W=%d pad=%d, Hm=%d Wm=%d stride=%d)", dy, dx, in->H, in->W, in->P, d->Hm, d->Wm, d->in_stride);
+            a.g[g].tap_off[t] = (dy * in->Wp + dx) * in->C;
+        }
+        if (d->in_coff[g] < 0 || d->in_coff[g] + d->cin > in->C || (d->in_coff[g] % 8)) RT_FAIL("op_conv: input channel slice out of range");
+        const int oyhi = (d->Hm - 1) * d->out_scale + d->out_oy[g], oxhi = (d->Wm - 1) * d->out_scale + d->out_ox[g];
+        if (out) {
+            if (d->out_coff[g] < 0 || d->out_coff[g] + d->cout > out->C || (d->out_coff[g] % 8)) RT_FAIL("op_conv: output channel slice out of range");
+            if (oyhi >= out->H || oxhi >= out->W || d->out_oy[g] < 0 || d->out_ox[g] < 0) RT_FAIL("op_conv: output pixel out of range");
+            if (out->B != in->B) RT_FAIL("op_conv: batch mismatch");
+        } else {
+            if (oyhi >= d->out_H || oxhi >= d->out_W) RT_FAIL("op_conv: NCHW output pixel out of range");
+        }
+        if (res) {
+            if (d->res_coff[g] < 0 || d->res_coff[g] + d->cout > res->C || (d->res_coff[g] % 8)) RT_FAIL("op_conv: residual channel slice out of range");
+            if (oyhi >= res->H || oxhi >= res->W) RT_FAIL("op_conv: residual pixel out of range");
+        }
+        a.g[g].in_coff = d->in_coff[g]; a.g[g].out_coff = d->out_coff[g]; a.g[g].res_coff = d->res_coff[g];
+        a.g[g].out_oy = d->out_oy[g]; a.g[g].out_ox = d->out_ox[g];
+    }
+    op.groups = d->groups; op.epi_nchw = d->out_nchw_f32 ? 1 : 0; op.out_slot = d->out_nchw_f32 - 1;
+    const double M = (double)a.M;
+    op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
+    op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0);
+    if (d->kernel == 0) {
+        const int BN = d->bn_tile;
+        if (BN != 16 && BN != 32 && BN != 64 && BN != 128) RT_FAIL("op_conv: bn_tile must be 16/32/64/128");
+        if (d->cin % 64) RT_FAIL("op_conv(mfma): cin=%d is not a multiple of 64", d->cin);
+        if (!d->out_nchw_f32 && (d->cout % BN)) RT_FAIL("op_conv(mfma): cout=%d is not a multiple of the tile %d", d->cout, BN);
+        const int cout_pad = (d->cout + BN - 1) / BN * BN;
+        a.cpt = d->cin / 64; a.ksteps = d->ntaps * a.cpt;
+        a.MT = (a.M + 127) / 128; a.NT = cout_pad / BN;
+        const size_t per_group = (size_t)cout_pad * a.ksteps * 64;
+        if (wbytes != per_group * d->groups * sizeof(f16)) RT_FAIL("op_conv(mfma): packed weight blob has %zu bytes, expected %zu", wbytes, per_group * d->groups * sizeof(f16));
+        if (bbytes != (size_t)cout_pad * d->groups * sizeof(float)) RT_FAIL("op_conv(mfma): bias blob has %zu bytes, expected %zu", bbytes, (size_t)cout_pad * d->groups * sizeof(float));
+        for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = cout_pad * g; }
+        op.kind = OP_CONV_MFMA; op.bn_tile = BN;
+        op.name = d->ntaps == 1 ? "conv1x1_mfma" : (d->ntaps == 4 ? "deconv4x4_phase_mfma" : "conv3x3_mfma");
+    } else {
+        if (d->groups != 1 || d->out_nchw_f32) RT_FAIL("op_conv(direct): groups/NCHW output unsupported");
+        if (!conv_direct_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(direct): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
+        if (wbytes != (size_t)d->ntaps * d->cin * d->cout * sizeof(f16)) RT_FAIL("op_conv(direct): weight blob size mismatch");
+        if (bbytes != (size_t)d->cout * sizeof(float)) RT_FAIL("op_conv(direct): bias blob size mismatch");
+        a.g[0].w_off = 0; a.g[0].bias_off = 0;
+        op.kind = OP_CONV_DIRECT;
+        op.name = "conv_direct_dot2";
+    }
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+extern "C" int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff,
+                                int channels, int ksize, int stride, int pad) {
+    Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
+    Tensor* out = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    if (!in || !out) RT_FAIL("op_maxpool: bad tensors");
+    if (channels % 8 || in_coff % 8 || out_coff % 8 || in_coff + channels > in->C || out_coff + channels > out->C) RT_FAIL("op_maxpool: bad channel slice");
+    if (pad > in->P) RT_FAIL("op_maxpool: input border %d narrower than pool padding %d", in->P, pad);
+    if ((out->H - 1) * stride - pad + ksize - 1 >= in->H + in->P || (out->W - 1) * stride - pad + ksize - 1 >= in->W + in->P) RT_FAIL("op_maxpool: window leaves the padded input");
+    Op op;
+    op.kind = OP_MAXPOOL; op.name = "maxpool";
+    PoolKArgs& a = op.pool;
+    a.in = in->base; a.out = out->base; a.B = in->B; a.Ho = out->H; a.Wo = out->W; a.C8 = channels / 8;
+    a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_P = in->P; a.in_coff = in_coff;
+    a.out_Hp = out->Hp; a.out_Wp = out->Wp; a.out_C = out->C; a.out_P = out->P; a.out_coff = out_coff;
+    a.ksize = ksize; a.stride = stride; a.pad = pad;
+    op.flops = 0;
+    op.bytes = 2.0 * in->B * channels * ((double)in->H * in->W + (double)out->H * out->W);
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_u, const int* u_tensors) {
+    Tensor* zi = ctx ? get_tensor(ctx, z_in) : nullptr;
+    Tensor* zo = ctx ? get_tensor(ctx, z_out) : nullptr;
+    if (!zi || !zo || n_u < 1 || n_u > 3 || !u_tensors) RT_FAIL("op_softmax_fuse: bad arguments");
+    if (zi->C != 256 || zo->C != 256 || zi->H != zo->H || zi->W != zo->W || zi->B != zo->B) RT_FAIL("op_softmax_fuse: z tensors must be 256-channel with equal shape");
+    Op op;
+    op.kind = OP_SOFTMAX; op.name = "softmax_fuse";
+    SoftmaxKArgs& a = op.sm;
+    memset(&a, 0, sizeof(a));
+    a.z_in = zi->base; a.z_out = zo->base; a.n_u = n_u;
+    a.B = zi->B; a.H = zi->H; a.W = zi->W; a.C = 256;
+    a.z_Hp = zo->Hp; a.z_Wp = zo->Wp; a.z_C = zo->C; a.z_P = zo->P;
+    a.zi_Hp = zi->Hp; a.zi_Wp = zi->Wp; a.zi_C = zi->C; a.zi_P = zi->P;
+    for (int i = 0; i < n_u; ++i) {
+        Tensor* u = get_tensor(ctx, u_tensors[i]);
+        if (!u || u->C != 256 || u->H != zi->H || u->W != zi->W || u->B != zi->B) RT_FAIL("op_softmax_fuse: u tensor %d mismatch", i);
+        a.u[i] = u->base; a.u_Hp[i] = u->Hp; a.u_Wp[i] = u->Wp; a.u_C[i] = u->C; a.u_P[i] = u->P;
+    }
+    a.rows_per_chunk = 2;
+    a.chunks = (a.H + a.rows_per_chunk - 1) / a.rows_per_chunk;
+    void* part = nullptr;
+    RT_HIP(hipMalloc(&part, (size_t)n_u * a.B * a.chunks * a.C * 2 * sizeof(float)));
+    ctx->extra.push_back(part);
+    a.partial = (float*)part;
+    op.flops = 0;
+    op.bytes = 2.0 * a.B * a.H * a.W * 256.0 * (2.0 * n_u + 2.0);
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_out[4]) {
+    hipError_t e = hipSuccess;
+    switch (op.kind) {
+        case OP_STEM: {
+            StemKArgs a = op.stem; a.in = d_in;
+            e = launch_stem(a, op.ksize, op.stem_cout, s);
+            break;
+        }
+        case OP_CONV_MFMA: {
+            ConvKArgs a = op.conv;
+            if (op.epi_nchw) a.out = d_out[op.out_slot];
+            e = launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
+            break;
+        }
+        case OP_CONV_DIRECT: e = launch_conv_direct(op.conv, 0, op.groups, s); break;
+        case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
+        case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;
+    }
+    if (e != hipSuccess) { rt_set_error("launch of op '%s' failed: %s", op.name.c_str(), hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
+    if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward: null argument");
+    for (int i = 0; i < 4; ++i) if (!d_out_logits[i]) RT_FAIL("forward: null logits buffer %d", i);
+    if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
+    const int n = (int)ctx->ops.size();
+    for (int i = 0; i < n; ++i) {
+        const bool probe = (i == ctx->probe_op);
+        const int slot = ctx->probe_count % PROBE_RING;
+        if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], (hipStream_t)stream));
+        if (launch_op(ctx->ops[i], (hipStream_t)stream, d_in, d_out_logits)) return 1;
+        if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], (hipStream_t)stream)); ctx->probe_count++; }
+    }
+    return 0;
+}
+
+extern "C" int rtm3d_probe_set(rtm3d_ctx* ctx, int op_index) {
+    if (!ctx || op_index >= (int)ctx->ops.size()) RT_FAIL("probe_set: bad op index");
+    if (ctx->probe_ev.empty() && op_index >= 0) {
+        ctx->probe_ev.resize(2 * PROBE_RING);
+        for (auto& e : ctx->probe_ev) RT_HIP(hipEventCreate(&e));
+    }
+    ctx->probe_op = op_index;
+    ctx->probe_count = 0;
+    return 0;
+}
+
+extern "C" int rtm3d_probe_read(rtm3d_ctx* ctx, double* avg_ms, int* count) {
+    if (!ctx || !avg_ms || !count) RT_FAIL("probe_read: null argument");
+    const int n = ctx->probe_count < PROBE_RING ? ctx->probe_count : PROBE_RING;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        RT_HIP(hipEventSynchronize(ctx->probe_ev[2 * i + 1]));
+        RT_HIP(hipEventElapsedTime(&ms, ctx->probe_ev[2 * i], ctx->probe_ev[2 * i + 1]));
+        sum += ms;
+    }
+    *avg_ms = n ? sum / n : 0.0;
+    *count = n;
+    return 0;
+}
+
+extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
+                                   float* h_ms, int cap, int* n_ops) {
+    if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward_timed: null argument");
+    const int n = (int)ctx->ops.size();
+    if (n_ops) *n_ops = n;
+    if (!h_ms) return 0;
+    if (cap < n) RT_FAIL("forward_timed: capacity %d < %d ops", cap, n);
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) RT_HIP(hipEventCreate(&e));
+    hipStream_t s = (hipStream_t)stream;
+    RT_HIP(hipEventRecord(ev[0], s));
+    for (int i = 0; i < n; ++i) {
+        if (launch_op(ctx->ops[i], s, d_in, d_out_logits)) return 1;
+        RT_HIP(hipEventRecord(ev[i + 1], s));
+    }
+    RT_HIP(hipEventSynchronize(ev[n]));
+    for (int i = 0; i < n; ++i) RT_HIP(hipEventElapsedTime(&h_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int rtm3d_op_info(rtm3d_ctx* ctx, int i, double* flops, double* bytes, const char** name) {
+    if (!ctx || i < 0 || i >= (int)ctx->ops.size()) RT_FAIL("op_info: index out of range");
+    if (flops) *flops = ctx->ops[i].flops;
+    if (bytes) *bytes = ctx->ops[i].bytes;
+    if (name) *name = ctx->ops[i].name.c_str();
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""Model facade with the reference's call surface (models/model.py:9-75) on top of
+librtm3d_hip.so.
+
+    model = create_model(cfg); model.to('cuda'); model.eval(); model.load_state_dict(sd)
+    (clses, m_scores, m_projs, v_projs_regress, bboxes_2d), pred_logits = model(imgs)
+
+``imgs`` is a float32 CUDA tensor (B, 3, H, W), H and W multiples of 32.  Everything numerical runs
+in the HIP library; this file only owns the fp32 state dict, caches one recorded plan per input
+shape and turns the fixed-size device outputs of the decode kernel into the reference's
+per-image lists (``None`` for images without detections, models/model.py:33-44).
+There is no CPU path: a CPU input tensor or a missing library raises.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import plan as plan_mod
+from .weights import parse_backbone, state_dict_spec, synth_state_dict
+
+
+class _Namespace(object):
+    """Place-holder for the sub-module attributes the reference exposes (model.backbone, ...)."""
+    def __init__(self, owner, prefix):
+        self._owner, self._prefix = owner, prefix
+
+    def state_dict(self):
+        n = len(self._prefix) + 1
+        return OrderedDict((k[n:], v) for k, v in self._owner._sd.items() if k.startswith(self._prefix + '.'))
+
+
+class Detections(object):
+    """Fixed-size device-resident results of one batch (no host synchronisation needed to make them)."""
+    __slots__ = ('n', 'cls', 'score', 'mproj', 'verts', 'bbox', 'topk')
+
+    def __init__(self, B, topk, device):
+        self.topk = topk
+        self.n = torch.zeros(B, dtype=torch.int32, device=device)
+        self.cls = torch.zeros(B * topk, dtype=torch.int64, device=device)
+        self.score = torch.zeros(B * topk, dtype=torch.float32, device=device)
+        self.mproj = torch.zeros(B * topk, 2, dtype=torch.float32, device=device)
+        self.verts = torch.zeros(B * topk, 8, 2, dtype=torch.float32, device=device)
+        self.bbox = torch.zeros(B * topk, 4, dtype=torch.float32, device=device)
+
+
+class Model(object):
+    def __init__(self, config, backbone=None):
+        self.config = config
+        self._backbone_name = backbone if isinstance(backbone, str) else config.MODEL.BACKBONE
+        parse_backbone(self._backbone_name)
+        if int(config.MODEL.OUT_CHANNELS) != 256 or int(config.MODEL.HEADER_NUM_CONV) != 2:
+            raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256, HEADER_NUM_CONV=2')
+        self.training = True                     # nn.Module default; detect.py:31 calls eval()
+        self.export = False
+        self._device = None
+        self._plans = {}
+        self._ws = {}
+        # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
+        self._sd = synth_state_dict(self._backbone_name, seed=0, style='init')
+        self.backbone = _Namespace(self, 'backbone')
+        self.kfpn_fusion = _Namespace(self, 'kfpn_fusion')
+        self.detect_header = _Namespace(self, 'detect_header')
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, state_dict, strict=True):
+        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name))
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError('Error(s) in loading state_dict: missing keys %s, unexpected keys %s' % (missing[:5], unexpected[:5]))
+        new = OrderedDict(self._sd)
+        for k, shape in want.items():
+            if k in state_dict:
+                v = torch.as_tensor(state_dict[k]).detach().cpu()
+                if tuple(v.shape) != tuple(shape):
+                    raise RuntimeError('size mismatch for %s: %s vs %s' % (k, tuple(v.shape), tuple(shape)))
+                new[k] = v.to(torch.int64) if k.endswith('num_batches_tracked') else v.to(torch.float32).contiguous()
+        self._sd = new
+        self._drop_plans()
+        return None
+
+    def _drop_plans(self):
+        for p in self._plans.values():
+            p.close()
+        self._plans = {}
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def to(self, device=None, *args, **kwargs):
+        if device is not None and not isinstance(device, torch.dtype):
+            d = torch.device(device)
+            if d.type != 'cuda':
+                raise RuntimeError('rtm3d_amd.Model runs on an AMD GPU only (got device %s); there is no CPU path' % d)
+            self._device = torch.device('cuda', d.index if d.index is not None else torch.cuda.current_device())
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device('cuda', device) if isinstance(device, int) else (device or 'cuda'))
+
+    def float(self):
+        return self
+
+    def parameters(self):
+        return (v for k, v in self._sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+
+    def modules(self):
+        return iter([self])
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    # ------------------------------------------------------------------ hot path
+    def _plan_for(self, B, H, W, device):
+        key = (B, H, W, device.index)
+        p = self._plans.get(key)
+        if p is None:
+            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W)
+            with torch.cuda.device(device):
+                p = plan_mod.RealizedPlan(ir, device.index)
+            self._plans[key] = p
+        return p
+
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected a (B, 3, H, W) tensor')
+        if not x.is_cuda:
+            raise RuntimeError('rtm3d_amd.Model.forward needs a CUDA (ROCm) tensor; there is no CPU path')
+        if x.dtype != torch.float32:
+            x = x.float()
+        return x.contiguous()
+
+    def forward_logits(self, x):
+        """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23)."""
+        x = self._check_input(x)
+        B, _, H, W = x.shape
+        dev = x.device
+        plan = self._plan_for(B, H, W, dev)
+        with torch.cuda.device(dev):
+            outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in (3, 16, 2, 2)]
+            plan.forward(torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), [o.data_ptr() for o in outs])
+        return tuple(outs)
+
+    def forward(self, x):
+        pred_logits = self.forward_logits(x)
+        if self.training:
+            # the reference returns the raw logits for its loss (models/model.py:24-25)
+            return pred_logits
+        return self.inference(pred_logits), pred_logits
+
+    def decode2d(self, pred_logits, out=None):
+        """Fixed-size device results of the 2D decode (no host sync)."""
+        main_kf, offs, moff = pred_logits[0], pred_logits[1], pred_logits[2]
+        for t in (main_kf, offs, moff):
+            if not t.is_cuda:
+                raise RuntimeError('rtm3d_amd.Model.inference needs CUDA (ROCm) tensors; there is no CPU path')
+        main_kf, offs, moff = (t.contiguous().float() for t in (main_kf, offs, moff))
+        B, K, H, W = main_kf.shape
+        topk = int(self.config.DETECTOR.TOPK_CANDIDATES)
+        dev = main_kf.device
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            if out is None:
+                out = Detections(B, topk, dev)
+            key = ('d2', B, K, H, W, dev.index)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = torch.empty(int(lib.rtm3d_decode2d_workspace_bytes(B, K, H, W)), dtype=torch.uint8, device=dev)
+                self._ws[key] = ws
+            _lib.check(lib.rtm3d_decode2d(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), main_kf.data_ptr(),
+                                          offs.data_ptr(), moff.data_ptr(), B, K, H, W,
+                                          float(self.config.DETECTOR.SCORE_THRESH), topk, float(self.config.MODEL.DOWN_SAMPLE),
+                                          ws.data_ptr(), out.n.data_ptr(), out.cls.data_ptr(), out.score.data_ptr(),
+                                          out.mproj.data_ptr(), out.verts.data_ptr(), out.bbox.data_ptr()), 'decode2d')
+        return out
+
+    def inference(self, pred_logits):
+        """Model.inference (models/model.py:29-75): per-image lists, ``None`` where nothing was kept."""
+        det = self.decode2d(pred_logits)
+        B, topk = det.n.shape[0], det.topk
+        n = det.n.cpu().tolist()                 # the only host synchronisation of the path
+        clses, m_scores, m_projs, v_projs_regress, bboxes_2d = ([None] * B for _ in range(5))
+        for i in range(B):
+            if n[i] == 0:
+                continue
+            s = slice(i * topk, i * topk + n[i])
+            clses[i], m_scores[i], m_projs[i] = det.cls[s], det.score[s], det.mproj[s]
+            v_projs_regress[i], bboxes_2d[i] = det.verts[s], det.bbox[s]
+        return clses, m_scores, m_projs, v_projs_regress, bboxes_2d
+
+    def forward_dict(self, x):
+        """Dict view of the eval outputs (offered in addition to the reference tuple)."""
+        (c, s, m, v, b), logits = self.eval().forward(x)
+        return {'clses': c, 'm_scores': s, 'm_projs': m, 'v_projs_regress': v, 'bboxes_2d': b,
+                'main_kf_logits': logits[0], 'offset_fr_main_logits': logits[1], 'main_offset_logits': logits[2],
+                'vertex_offset_logits': logits[3]}
+
+    # ------------------------------------------------------------------ fused device pipeline
+    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0)):
+        """forward + 2D decode + 3D decode, all stream-ordered on the device (no host sync).
+        K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D)."""
+        from .model_utils import decode3d_slots
+        logits = self.forward_logits(x)
+        det = self.decode2d(logits)
+        dim_ref = dim_ref if dim_ref is not None else self.config.DETECTOR.dim_ref
+        boxes = decode3d_slots(det, K_per_image, dim_ref, ref_loc)
+        return det, boxes, logits

@@ -1,0 +1,106 @@
+"""3D box decode with the reference's signature (utils/model_utils.py:264-312) on the HIP kernel.
+
+``optim_decode_bbox3d(clses, bbox3d_projs, K, ref_dim, ref_loc) -> ParamList`` takes the numpy
+arrays detect.py:71-74 passes and returns the same fields (class, Ry, dimension, location, K) for
+the objects whose final reprojection error is < 0.1.  The optimisation itself (fp64 L-BFGS-B, one
+GPU lane per object) runs in librtm3d_hip.so; there is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ParamList import ParamList
+
+FUN_ACCEPT = 0.1      # utils/model_utils.py:298
+
+
+def _device(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError('rtm3d_amd.model_utils needs an AMD GPU (ROCm); there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+class Boxes3D(object):
+    """Device-resident raw solver output for B*topk slots (+ derived box parameters)."""
+    __slots__ = ('x', 'fun', 'nit', 'status')
+
+    def __init__(self, n, device):
+        self.x = torch.zeros(n, 8, dtype=torch.float64, device=device)
+        self.fun = torch.full((n,), float('inf'), dtype=torch.float64, device=device)
+        self.nit = torch.zeros(n, dtype=torch.int32, device=device)
+        self.status = torch.full((n,), -1, dtype=torch.int32, device=device)
+
+    @property
+    def kept(self):
+        return (self.status >= 0) & (self.fun < FUN_ACCEPT)
+
+    @property
+    def Ry(self):                      # utils/model_utils.py:300
+        return torch.atan2(self.x[:, 0], self.x[:, 1])
+
+    @property
+    def dimension(self):               # :302  (h, w, l)
+        return self.x[:, [3, 4, 2]]
+
+    @property
+    def location(self):                # :303
+        return self.x[:, 5:8]
+
+
+def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0)):
+    """Stream-ordered 3D decode of the slots produced by Model.decode2d (no host sync)."""
+    lib = _lib.load()
+    dev = det.n.device
+    B, topk = det.n.shape[0], det.topk
+    K = torch.as_tensor(K_per_image, dtype=torch.float64, device=dev).reshape(B, 9).contiguous()
+    dim = torch.as_tensor(np.asarray(dim_ref, np.float64), device=dev).contiguous()
+    loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev).contiguous()
+    out = Boxes3D(B * topk, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rtm3d_decode3d_slots(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, topk,
+                                            det.n.data_ptr(), det.cls.data_ptr(), det.verts.data_ptr(), K.data_ptr(),
+                                            dim.data_ptr(), int(dim.shape[0]), loc.data_ptr(), out.x.data_ptr(),
+                                            out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode3d_slots')
+    return out
+
+
+def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None):
+    """Raw solver results for N objects: (x (N,8), fun (N,), nit (N,), status (N,)) as numpy."""
+    lib = _lib.load()
+    dev = _device(device)
+    clses = np.asarray(clses).reshape(-1)
+    N = clses.shape[0]
+    if N == 0:
+        return np.zeros((0, 8)), np.zeros((0,)), np.zeros((0,), np.int32), np.zeros((0,), np.int32)
+    uv = np.ascontiguousarray(np.asarray(bbox3d_projs, np.float32).reshape(N, 16))
+    K = np.asarray(K, np.float64)
+    Kn = np.ascontiguousarray(np.broadcast_to(K.reshape(-1, 9), (N, 9)) if K.size == 9 else K.reshape(N, 9))
+    with torch.cuda.device(dev):
+        d_cls = torch.as_tensor(clses.astype(np.int64), device=dev)
+        d_uv = torch.as_tensor(uv, device=dev)
+        d_K = torch.as_tensor(Kn, device=dev)
+        d_dim = torch.as_tensor(np.asarray(ref_dim, np.float64), device=dev).contiguous()
+        d_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev).contiguous()
+        out = Boxes3D(N, dev)
+        _lib.check(lib.rtm3d_decode3d(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), N, d_cls.data_ptr(),
+                                      d_uv.data_ptr(), d_K.data_ptr(), d_dim.data_ptr(), int(d_dim.shape[0]), d_loc.data_ptr(),
+                                      out.x.data_ptr(), out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode3d')
+        return out.x.cpu().numpy(), out.fun.cpu().numpy(), out.nit.cpu().numpy(), out.status.cpu().numpy()
+
+
+def optim_decode_bbox3d(clses, bbox3d_projs, K, ref_dim, ref_loc):
+    """Drop-in for utils/model_utils.py:264-312."""
+    clses = np.asarray(clses).reshape(-1)
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    x, fun, _, _ = solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc)
+    keep = fun < FUN_ACCEPT
+    xs = x[keep]
+    out = ParamList((640, 640))
+    out.add_field('class', [c for c, k in zip(clses.tolist(), keep.tolist()) if k])
+    out.add_field('Ry', np.arctan2(xs[:, 0], xs[:, 1]) if len(xs) else np.array([]))
+    out.add_field('dimension', xs[:, [3, 4, 2]] if len(xs) else np.zeros((0, 3)))
+    out.add_field('location', xs[:, 5:8] if len(xs) else np.zeros((0, 3)))
+    out.add_field('K', np.repeat(K.reshape(1, 9), len(xs), axis=0) if len(xs) else np.zeros((0, 9)))
+    return out

@@ -1,0 +1,468 @@
+"""Host-side plan builder: reference state-dict -> list of kernel launches for librtm3d_hip.so.
+
+Orchestration only (BASELINE north_star: "host code stays Python for weight loading and
+orchestration").  ``build_plan`` walks the architecture once and emits a small IR:
+
+  tensors : padded NHWC fp16 activations  {H, W, C, pad}
+  ops     : stem | conv | maxpool | softmax   with BatchNorm already folded into weights/bias
+
+``realize`` packs the weights for the chosen kernel and records the plan into a runtime context
+through the C ABI.  The IR is plain numpy so the wiring (channel slices instead of torch.cat,
+sub-pixel phases of the transposed convolutions, BN folding) can be checked on a CPU-only
+machine by tests/plan_interp.py.
+
+Graph sources: models/nets/dla.py:186-210,322-332 (DLA-34 trees), models/nets/resnet.py:143-158,
+200-211 (ResNet), models/nets/keypoint_fpn_fusion.py:35-69 (neck), models/nets/header.py:40-46.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, HEADS
+
+BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
+
+
+class Slice(object):
+    """Channels [coff, coff+C) of a plan tensor."""
+    def __init__(self, tid, coff, C):
+        self.tid, self.coff, self.C = tid, coff, C
+
+
+class Plan(object):
+    def __init__(self, B, H, W):
+        self.B, self.H, self.W = B, H, W
+        self.tensors = []
+        self.ops = []
+        self.named = {}      # debug names -> Slice (stage outputs, for parity tests)
+
+    # ---- IR construction
+    def tensor(self, H, W, C, pad, name=None):
+        self.tensors.append({'H': H, 'W': W, 'C': C, 'pad': pad})
+        s = Slice(len(self.tensors) - 1, 0, C)
+        if name:
+            self.named[name] = s
+        return s
+
+    def sub(self, s, coff, C, name=None):
+        r = Slice(s.tid, s.coff + coff, C)
+        if name:
+            self.named[name] = r
+        return r
+
+    def dims(self, s):
+        t = self.tensors[s.tid]
+        return t['H'], t['W']
+
+    def conv(self, inp, out, w, bias, stride=1, dil=1, relu=False, res=None, name='', out_nchw=0, out_hw=None):
+        """w: (cout, cin, k, k) fp32 with BN folded; padding = dil*(k-1)//2 (all reference convs)."""
+        cout, cin, k, _ = w.shape
+        assert inp.C == cin, (name, inp.C, cin)
+        pad = dil * (k - 1) // 2
+        taps = [(ky * dil - pad, kx * dil - pad) for ky in range(k) for kx in range(k)]
+        wt = np.stack([w[:, :, ky, kx] for ky in range(k) for kx in range(k)], 0)[None]   # (1, taps, cout, cin)
+        Hi, Wi = self.dims(inp)
+        Hm, Wm = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+        if out is not None:
+            assert out.C == cout and self.dims(out) == (Hm, Wm), (name, out.C, cout, self.dims(out), (Hm, Wm))
+        self.ops.append({'op': 'conv', 'name': name, 'inp': [inp], 'out': [out], 'res': [res], 'Hm': Hm, 'Wm': Wm,
+                         'in_stride': stride, 'out_scale': 1, 'cin': cin, 'cout': cout, 'groups': 1,
+                         'taps': [taps], 'out_off': [(0, 0)], 'relu': relu, 'w': wt.astype(np.float32),
+                         'bias': np.asarray(bias, np.float32)[None], 'out_nchw': out_nchw,
+                         'out_hw': out_hw or (Hm, Wm)})
+
+    def grouped_conv(self, inps, outs, ws, biases, dil=1, relu=False, name=''):
+        """Same-shape 3x3 convs on different channel slices in one launch (the four head branches)."""
+        G = len(inps)
+        cout, cin, k, _ = ws[0].shape
+        pad = dil * (k - 1) // 2
+        taps = [(ky * dil - pad, kx * dil - pad) for ky in range(k) for kx in range(k)]
+        wt = np.stack([np.stack([w[:, :, ky, kx] for ky in range(k) for kx in range(k)], 0) for w in ws], 0)
+        Hm, Wm = self.dims(inps[0])
+        self.ops.append({'op': 'conv', 'name': name, 'inp': list(inps), 'out': list(outs), 'res': [None] * G,
+                         'Hm': Hm, 'Wm': Wm, 'in_stride': 1, 'out_scale': 1, 'cin': cin, 'cout': cout, 'groups': G,
+                         'taps': [taps] * G, 'out_off': [(0, 0)] * G, 'relu': relu, 'w': wt.astype(np.float32),
+                         'bias': np.stack([np.asarray(b, np.float32) for b in biases], 0), 'out_nchw': 0,
+                         'out_hw': (Hm, Wm)})
+
+    def deconv(self, inp, out, w, name=''):
+        """ConvTranspose2d(k=4, s=2, p=1, bias=False) (models/nets/module.py:7-15), w: (cin, cout, 4, 4),
+        as four sub-pixel phases: output row 2y+py receives input rows {y, y-1} (py=0, ky=1,3) or
+        {y+1, y} (py=1, ky=0,2); same along x.  No zero insertion."""
+        cin, cout = w.shape[0], w.shape[1]
+        assert inp.C == cin and out.C == cout
+        Hi, Wi = self.dims(inp)
+        assert self.dims(out) == (2 * Hi, 2 * Wi)
+        kd = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}     # phase -> [(k index, input offset)]
+        taps, wts, offs = [], [], []
+        for py in (0, 1):
+            for px in (0, 1):
+                tp, wp = [], []
+                for ky, dy in kd[py]:
+                    for kx, dx in kd[px]:
+                        tp.append((dy, dx))
+                        wp.append(w[:, :, ky, kx].T)           # (cout, cin)
+                taps.append(tp); wts.append(np.stack(wp, 0)); offs.append((py, px))
+        self.ops.append({'op': 'conv', 'name': name, 'inp': [inp] * 4, 'out': [out] * 4, 'res': [None] * 4,
+                         'Hm': Hi, 'Wm': Wi, 'in_stride': 1, 'out_scale': 2, 'cin': cin, 'cout': cout, 'groups': 4,
+                         'taps': taps, 'out_off': offs, 'relu': False, 'w': np.stack(wts, 0).astype(np.float32),
+                         'bias': np.zeros((4, cout), np.float32), 'out_nchw': 0, 'out_hw': (2 * Hi, 2 * Wi)})
+
+    def maxpool(self, inp, out, k, stride, pad, name=''):
+        assert inp.C == out.C
+        self.ops.append({'op': 'maxpool', 'name': name, 'inp': inp, 'out': out, 'k': k, 'stride': stride, 'pad': pad})
+
+    def stem(self, out, w, bias, stride, name=''):
+        cout, cin, k, _ = w.shape
+        assert cin == 3 and out.C == cout and out.coff == 0
+        self.ops.append({'op': 'stem', 'name': name, 'out': out, 'k': k, 'stride': stride, 'pad': (k - 1) // 2,
+                         'cout': cout, 'w': np.ascontiguousarray(w.transpose(2, 3, 1, 0)).astype(np.float32),
+                         'bias': np.asarray(bias, np.float32)})
+
+    def softmax_fuse(self, z_in, z_out, us, name=''):
+        self.ops.append({'op': 'softmax', 'name': name, 'z_in': z_in, 'z_out': z_out, 'us': list(us)})
+
+    def total_flops(self):
+        f = 0.0
+        for op in self.ops:
+            if op['op'] == 'conv':
+                f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['groups'] * op['cin'] * len(op['taps'][0]) * op['cout']
+            elif op['op'] == 'stem':
+                H, W = self.dims(op['out'])
+                f += 2.0 * self.B * H * W * op['k'] * op['k'] * 3 * op['cout']
+        return f
+
+
+# ------------------------------------------------------------------------------------------
+def _np(sd, key):
+    return sd[key].detach().cpu().numpy().astype(np.float64)
+
+
+def fold_bn(sd, conv, bn=None):
+    """conv weight (+bias) followed by eval-mode BatchNorm(eps=1e-4) -> (w', b') in fp32."""
+    w = _np(sd, conv + '.weight')
+    b = _np(sd, conv + '.bias') if (conv + '.bias') in sd else np.zeros(w.shape[0])
+    if bn is not None:
+        s = _np(sd, bn + '.weight') / np.sqrt(_np(sd, bn + '.running_var') + BN_EPS)
+        w = w * s[:, None, None, None]
+        b = (b - _np(sd, bn + '.running_mean')) * s + _np(sd, bn + '.bias')
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def _dla_block(P, sd, p, x, out, stride, residual, mid_name=None):
+    """BasicBlock (models/nets/dla.py:86-100): relu(bn2(conv2(relu(bn1(conv1 x)))) + residual)."""
+    Ho, Wo = P.dims(out)
+    mid = P.tensor(Ho, Wo, out.C, 1, name=mid_name)
+    w, b = fold_bn(sd, p + '.conv1', p + '.norm1')
+    P.conv(x, mid, w, b, stride=stride, relu=True, name=p + '.conv1')
+    w, b = fold_bn(sd, p + '.conv2', p + '.norm2')
+    P.conv(mid, out, w, b, relu=True, res=residual, name=p + '.conv2')
+
+
+def _dla_tree1(P, sd, p, x, bottom, cat, cin, cout, stride, extra):
+    """Level-1 Tree (models/nets/dla.py:186-206).  `cat` is the root's input: [x2 | x1 | children...];
+    children were already written into their slices by the caller.  Returns nothing; root output is
+    written to `extra['out']`."""
+    if cin != cout:
+        Hc, Wc = P.dims(cat)
+        resid = P.tensor(Hc, Wc, cout, 0)
+        w, b = fold_bn(sd, p + '.project.0', p + '.project.1')
+        P.conv(bottom, resid, w, b, name=p + '.project')
+    else:
+        resid = bottom
+    x2s, x1s = P.sub(cat, 0, cout), P.sub(cat, cout, cout)
+    _dla_block(P, sd, p + '.tree1', x, x1s, stride, resid)
+    _dla_block(P, sd, p + '.tree2', x1s, x2s, 1, x1s)
+    w, b = fold_bn(sd, p + '.root.conv', p + '.root.norm')
+    P.conv(cat, extra['out'], w, b, relu=True, name=p + '.root')
+
+
+def _build_dla(P, sd, H, W, feat_out):
+    ch = DLA34_CHANNELS
+    t_base = P.tensor(H, W, ch[0], 1, name='base')
+    w, b = fold_bn(sd, 'backbone.base_layer.0', 'backbone.base_layer.1')
+    P.stem(t_base, w, b, 1, name='backbone.base_layer')
+    t_l0 = P.tensor(H, W, ch[0], 1, name='level0')
+    w, b = fold_bn(sd, 'backbone.level0.0', 'backbone.level0.1')
+    P.conv(t_base, t_l0, w, b, relu=True, name='backbone.level0')
+    t_l1 = P.tensor(H // 2, W // 2, ch[1], 1, name='level1')
+    w, b = fold_bn(sd, 'backbone.level1.0', 'backbone.level1.1')
+    P.conv(t_l0, t_l1, w, b, stride=2, relu=True, name='backbone.level1')
+    x = t_l1
+    for i in range(2, 6):
+        p = 'backbone.level%d' % i
+        cin, cout = ch[i - 1], ch[i]
+        Hi, Wi = P.dims(x)
+        Ho, Wo = Hi // 2, Wi // 2
+        out = feat_out[i - 2]
+        if DLA34_LEVELS[i] == 1:
+            level_root = i > 2
+            cat = P.tensor(Ho, Wo, 2 * cout + (cin if level_root else 0), 1)
+            if level_root:
+                bottom = P.sub(cat, 2 * cout, cin)
+            else:
+                bottom = P.tensor(Ho, Wo, cin, 0)
+            P.maxpool(x, bottom, 2, 2, 0, name=p + '.downsample')
+            _dla_tree1(P, sd, p, x, bottom, cat, cin, cout, 2, {'out': out})
+        else:
+            # level-2 tree with level_root: final root input = [x2' | x1' | bottom | x1_outer]
+            cat2 = P.tensor(Ho, Wo, 3 * cout + cin, 1)
+            bottom = P.sub(cat2, 2 * cout, cin)
+            x1_outer = P.sub(cat2, 2 * cout + cin, cout)
+            P.maxpool(x, bottom, 2, 2, 0, name=p + '.downsample')
+            # (the outer tree's own `project` output is never consumed: models/nets/dla.py:195-202)
+            cat1 = P.tensor(Ho, Wo, 2 * cout, 1)
+            _dla_tree1(P, sd, p + '.tree1', x, bottom, cat1, cin, cout, 2, {'out': x1_outer})
+            _dla_tree1(P, sd, p + '.tree2', x1_outer, x1_outer, cat2, cout, cout, 1, {'out': out})
+        x = out
+
+
+def _build_resnet(P, sd, H, W, depth, feat_out):
+    t_c1 = P.tensor(H // 2, W // 2, 64, 1, name='conv1')
+    w, b = fold_bn(sd, 'backbone.conv1', 'backbone.bn1')
+    P.stem(t_c1, w, b, 2, name='backbone.conv1')
+    x = P.tensor(H // 4, W // 4, 64, 1, name='pool')
+    P.maxpool(t_c1, x, 3, 2, 1, name='backbone.maxpool')
+    inpl = 64
+    for li, (pl, nb) in enumerate(zip([64, 128, 256, 512], RESNET_BLOCKS[depth])):
+        for bi in range(nb):
+            p = 'backbone.layer%d.%d' % (li + 1, bi)
+            stride = 2 if (li > 0 and bi == 0) else 1
+            Hi, Wi = P.dims(x)
+            Ho, Wo = Hi // stride, Wi // stride
+            last = bi == nb - 1
+            out = feat_out[li] if last else P.tensor(Ho, Wo, pl, 1)
+            mid = P.tensor(Ho, Wo, pl, 1)
+            w, b = fold_bn(sd, p + '.conv1', p + '.bn1')
+            P.conv(x, mid, w, b, stride=stride, relu=True, name=p + '.conv1')
+            if bi == 0 and (stride != 1 or inpl != pl):
+                resid = P.tensor(Ho, Wo, pl, 0)
+                w, b = fold_bn(sd, p + '.downsample.0', p + '.downsample.1')
+                P.conv(x, resid, w, b, stride=stride, name=p + '.downsample')
+            else:
+                resid = x
+            w, b = fold_bn(sd, p + '.conv2', p + '.bn2')
+            P.conv(mid, out, w, b, relu=True, res=resid, name=p + '.conv2')
+            x = out
+            inpl = pl
+
+
+def build_plan(state_dict, backbone, B, H, W):
+    """state_dict: reference key names -> torch tensors.  H, W multiples of 32."""
+    kind, depth = parse_backbone(backbone)
+    if H % 32 or W % 32:
+        raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
+    sd = state_dict
+    P = Plan(B, H, W)
+    oc = 256
+    fch = [64, 128, 256, 512]
+    fh = [(H // s, W // s) for s in (4, 8, 16, 32)]
+    # neck concat buffers [up(256) | backbone feature]; the backbone writes its slice directly
+    ncat = [P.tensor(fh[i][0], fh[i][1], oc + fch[i], 1) for i in range(3)]
+    feat = [P.sub(ncat[i], oc, fch[i], name='feat%d' % i) for i in range(3)]
+    feat.append(P.tensor(fh[3][0], fh[3][1], fch[3], 0, name='feat3'))
+    if kind == 'dla':
+        _build_dla(P, sd, H, W, feat)
+    else:
+        _build_resnet(P, sd, H, W, depth, feat)
+
+    # ---- neck (models/nets/keypoint_fpn_fusion.py:35-46)
+    hs = [None] * 4
+    x_top = feat[3]
+    for i in (3, 2, 1):
+        L = i + 2
+        hs[i] = P.tensor(fh[i][0], fh[i][1], oc, 1, name='kfpn_h%d' % L)
+        w, b = fold_bn(sd, 'kfpn_fusion.kfpn_head%d' % L)
+        P.conv(x_top, hs[i], w, b, name='kfpn_head%d' % L)
+        P.deconv(hs[i], P.sub(ncat[i - 1], 0, oc), _np(sd, 'kfpn_fusion.kfpn_up%d.conv_tran.weight' % L).astype(np.float32),
+                 name='kfpn_up%d' % L)
+        x_top = P.tensor(fh[i - 1][0], fh[i - 1][1], fch[i - 1], 0, name='kfpn_p%d' % (L - 1))
+        w, b = fold_bn(sd, 'kfpn_fusion.kfpn_proj%d' % L)
+        P.conv(ncat[i - 1], x_top, w, b, name='kfpn_proj%d' % L)
+    z0 = P.tensor(fh[0][0], fh[0][1], oc, 0, name='z0')
+    w, b = fold_bn(sd, 'kfpn_fusion.kfpn_head2')
+    P.conv(x_top, z0, w, b, name='kfpn_head2')
+    # ---- fusion (keypoint_fpn_fusion.py:60-69): z = z0 + sum_i up^i(h_i) * softmax(up^i(h_i))
+    us = []
+    for i in (3, 2, 1):
+        u = hs[i]
+        for j in range(i):
+            last = j == i - 1
+            Hu, Wu = P.dims(u)
+            nu = P.tensor(2 * Hu, 2 * Wu, oc, 0 if last else 1, name=('u%d' % (i + 2)) if last else None)
+            P.deconv(u, nu, _np(sd, 'kfpn_fusion.fusion_up%d.%d.conv_tran.weight' % (i + 2, j)).astype(np.float32),
+                     name='fusion_up%d.%d' % (i + 2, j))
+            u = nu
+        us.append(u)
+    z = P.tensor(fh[0][0], fh[0][1], oc, 6, name='z')
+    P.softmax_fuse(z0, z, us, name='kfpn_softmax_fuse')
+
+    # ---- heads (models/nets/header.py:13-46): d6 conv of all four branches fused into one 256->1024 conv
+    h1 = P.tensor(fh[0][0], fh[0][1], 4 * oc, 1, name='h1')
+    h2 = P.tensor(fh[0][0], fh[0][1], 4 * oc, 1, name='h2')
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in HEADS])
+    P.conv(z, h1, np.concatenate(ws, 0), np.concatenate(bs, 0), dil=6, relu=True, name='heads.conv_d6')
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in HEADS])
+    P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(4)], [P.sub(h2, g * oc, oc) for g in range(4)], ws, bs,
+                   relu=True, name='heads.conv_d1')
+    for g, (seq, last, cout) in enumerate(HEADS):
+        w, b = fold_bn(sd, 'detect_header.%s.%s' % (seq, last))
+        P.conv(P.sub(h2, g * oc, oc), None, w, b, name='heads.%s' % last, out_nchw=g + 1, out_hw=fh[0])
+    return P
+
+
+# ------------------------------------------------------------------------------------------ realize
+def choose_bn_tile(cout, M):
+    """Output-channel tile of the MFMA kernel: as wide as the layer allows while still giving
+    >= ~2 workgroups per CU (256 CUs) so small late-stage layers fill the chip."""
+    if cout < 32:
+        return 16
+    if cout < 64:
+        return 32
+    if cout % 128 == 0 and (M // 128) * (cout // 128) >= 512:
+        return 128
+    return 64
+
+
+def pack_mfma_weights(wt, bn):
+    """wt: (taps, cout, cin) fp32 -> fp16 [ntile][kstep=(tap, cin/64)][bn rows][8 chunks][8] with the
+    LDS bank swizzle (chunk ^= row & 7) baked in (see conv_mfma.hip)."""
+    taps, cout, cin = wt.shape
+    cpt = cin // 64
+    cout_pad = (cout + bn - 1) // bn * bn
+    w = np.zeros((taps, cout_pad, cin), np.float32)
+    w[:, :cout] = wt
+    w = w.reshape(taps, cout_pad // bn, bn, cpt, 8, 8)              # t, nt, r, q, c, e
+    w = w.transpose(1, 0, 3, 2, 4, 5)                               # nt, t, q, r, c, e
+    r = np.arange(bn)[:, None]
+    cs = np.arange(8)[None, :]
+    src = cs ^ (r & 7)                                              # chunk stored at position cs of row r
+    w = w[:, :, :, r, src, :]
+    return np.ascontiguousarray(w).astype(np.float16).reshape(-1), cout_pad
+
+
+def pack_direct_weights(wt):
+    """wt: (taps, cout, cin) -> fp16 [tap][cin/2][cout][2]."""
+    taps, cout, cin = wt.shape
+    w = wt.transpose(0, 2, 1).reshape(taps, cin // 2, 2, cout).transpose(0, 1, 3, 2)
+    return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
+
+
+class RealizedPlan(object):
+    """A Plan recorded into a librtm3d_hip context."""
+    def __init__(self, plan, device_index):
+        lib = _lib.load()
+        self.lib, self.plan = lib, plan
+        ctx = ctypes.c_void_p()
+        _lib.check(lib.rtm3d_ctx_create(int(device_index), ctypes.byref(ctx)), 'ctx_create')
+        self.ctx = ctx
+        self._keep = []
+        self.tids = []
+        for t in plan.tensors:
+            tid = ctypes.c_int()
+            _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'], t['pad'], ctypes.byref(tid)), 'tensor_create')
+            self.tids.append(tid.value)
+        for op in plan.ops:
+            getattr(self, '_op_' + op['op'])(op)
+
+    def _blob(self, arr):
+        arr = np.ascontiguousarray(arr)
+        bid = ctypes.c_int()
+        _lib.check(self.lib.rtm3d_blob_create(self.ctx, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, ctypes.byref(bid)), 'blob_create')
+        return bid.value
+
+    def _op_stem(self, op):
+        _lib.check(self.lib.rtm3d_op_stem(self.ctx, self.tids[op['out'].tid], op['k'], op['stride'], op['pad'], op['cout'],
+                                          self._blob(op['w']), self._blob(op['bias'])), 'op_stem ' + op['name'])
+
+    def _op_conv(self, op):
+        d = _lib.ConvDesc()
+        G = op['groups']
+        d.in_tensor = self.tids[op['inp'][0].tid]
+        d.out_tensor = self.tids[op['out'][0].tid] if op['out'][0] is not None else -1
+        d.res_tensor = self.tids[op['res'][0].tid] if op['res'][0] is not None else -1
+        d.Hm, d.Wm, d.in_stride, d.out_scale = op['Hm'], op['Wm'], op['in_stride'], op['out_scale']
+        d.cin, d.cout, d.groups, d.ntaps = op['cin'], op['cout'], G, len(op['taps'][0])
+        for g in range(G):
+            assert op['inp'][g].tid == op['inp'][0].tid
+            d.in_coff[g] = op['inp'][g].coff
+            d.out_coff[g] = op['out'][g].coff if op['out'][g] is not None else 0
+            d.res_coff[g] = op['res'][g].coff if op['res'][g] is not None else 0
+            d.out_oy[g], d.out_ox[g] = op['out_off'][g]
+            for t, (dy, dx) in enumerate(op['taps'][g]):
+                d.tap_dy[g][t], d.tap_dx[g][t] = dy, dx
+        d.relu = 1 if op['relu'] else 0
+        d.out_nchw_f32 = op['out_nchw']
+        d.out_H, d.out_W = op['out_hw']
+        M = self.plan.B * op['Hm'] * op['Wm']
+        if op['cin'] % 64 == 0:
+            bn = choose_bn_tile(op['cout'], M)
+            packed, biases = [], []
+            for g in range(G):
+                pw, cout_pad = pack_mfma_weights(op['w'][g], bn)
+                packed.append(pw)
+                bb = np.zeros(cout_pad, np.float32)
+                bb[:op['cout']] = op['bias'][g]
+                biases.append(bb)
+            d.kernel, d.bn_tile = 0, bn
+            d.w_blob, d.bias_blob = self._blob(np.concatenate(packed)), self._blob(np.concatenate(biases))
+        else:
+            assert G == 1
+            d.kernel, d.bn_tile = 1, 0
+            d.w_blob, d.bias_blob = self._blob(pack_direct_weights(op['w'][0])), self._blob(op['bias'][0])
+        _lib.check(self.lib.rtm3d_op_conv(self.ctx, ctypes.byref(d)), 'op_conv ' + op['name'])
+
+    def _op_maxpool(self, op):
+        _lib.check(self.lib.rtm3d_op_maxpool(self.ctx, self.tids[op['inp'].tid], op['inp'].coff, self.tids[op['out'].tid],
+                                             op['out'].coff, op['inp'].C, op['k'], op['stride'], op['pad']), 'op_maxpool ' + op['name'])
+
+    def _op_softmax(self, op):
+        us = (ctypes.c_int * len(op['us']))(*[self.tids[u.tid] for u in op['us']])
+        _lib.check(self.lib.rtm3d_op_softmax_fuse(self.ctx, self.tids[op['z_in'].tid], self.tids[op['z_out'].tid], len(op['us']), us),
+                   'op_softmax_fuse')
+
+    # ---- execution
+    def forward(self, stream, d_in, d_out4):
+        outs = (ctypes.c_void_p * 4)(*d_out4)
+        _lib.check(self.lib.rtm3d_forward(self.ctx, ctypes.c_void_p(stream), ctypes.c_void_p(d_in), outs), 'forward')
+
+    def forward_timed(self, stream, d_in, d_out4):
+        outs = (ctypes.c_void_p * 4)(*d_out4)
+        n = ctypes.c_int()
+        _lib.check(self.lib.rtm3d_forward_timed(self.ctx, ctypes.c_void_p(stream), ctypes.c_void_p(d_in), outs, None, 0, ctypes.byref(n)), 'forward_timed')
+        ms = (ctypes.c_float * n.value)()
+        _lib.check(self.lib.rtm3d_forward_timed(self.ctx, ctypes.c_void_p(stream), ctypes.c_void_p(d_in), outs, ms, n.value, ctypes.byref(n)), 'forward_timed')
+        info = []
+        for i in range(n.value):
+            fl, by, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_char_p()
+            _lib.check(self.lib.rtm3d_op_info(self.ctx, i, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(nm)), 'op_info')
+            info.append({'kernel': nm.value.decode(), 'name': self.plan.ops[i]['name'], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
+        return info
+
+    def probe_set(self, op_index):
+        _lib.check(self.lib.rtm3d_probe_set(self.ctx, int(op_index)), 'probe_set')
+
+    def probe_read(self):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.rtm3d_probe_read(self.ctx, ctypes.byref(ms), ctypes.byref(n)), 'probe_read')
+        return ms.value, n.value
+
+    def download(self, s):
+        """Debug: fp32 NCHW copy of a Slice."""
+        t = self.plan.tensors[s.tid]
+        out = np.empty((self.plan.B, s.C, t['H'], t['W']), np.float32)
+        _lib.check(self.lib.rtm3d_tensor_download(self.ctx, self.tids[s.tid], s.coff, s.C, out.ctypes.data_as(ctypes.c_void_p)), 'tensor_download')
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.lib.rtm3d_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,91 @@
+"""CPU interpreter of the plan IR (rtm3d_amd/plan.py) - TEST INFRASTRUCTURE, not a product path.
+
+Executes the recorded ops with PyTorch-CPU on padded NHWC buffers exactly as the HIP runtime
+addresses them (channel slices, tap offsets, sub-pixel phases, zero borders), so the host-side
+graph wiring and BatchNorm folding can be validated against the oracle without a GPU.
+With ``half=True`` weights and stored activations are rounded to fp16 (fp32 accumulate), which
+predicts the numerical error of the fp16 MFMA path.
+"""
+import numpy as np
+import torch
+
+
+def run_plan(plan, x_nchw, half=False):
+    B = plan.B
+    rnd = (lambda t: t.half().float()) if half else (lambda t: t)
+    bufs = []
+    for t in plan.tensors:
+        bufs.append(torch.zeros(B, t['H'] + 2 * t['pad'], t['W'] + 2 * t['pad'], t['C']))
+    outs = [None] * 4
+
+    def view(s, extra=0):
+        t = plan.tensors[s.tid]
+        return bufs[s.tid], t['pad'], t['H'], t['W']
+
+    for op in plan.ops:
+        if op['op'] == 'stem':
+            o = op['out']
+            w = torch.from_numpy(op['w']).permute(3, 2, 0, 1).contiguous()       # (co, ci, ky, kx)
+            y = torch.nn.functional.conv2d(x_nchw, w, torch.from_numpy(op['bias']), op['stride'], op['pad']).relu()
+            buf, P, H, W = view(o)
+            buf[:, P:P + H, P:P + W, o.coff:o.coff + o.C] = rnd(y.permute(0, 2, 3, 1))
+        elif op['op'] == 'conv':
+            Hm, Wm, s, sc = op['Hm'], op['Wm'], op['in_stride'], op['out_scale']
+            for g in range(op['groups']):
+                inp = op['inp'][g]
+                ibuf, Pi, Hi, Wi = view(inp)
+                acc = torch.zeros(B, Hm, Wm, op['cout'])
+                wg = rnd(torch.from_numpy(op['w'][g]))                            # (taps, cout, cin)
+                for t, (dy, dx) in enumerate(op['taps'][g]):
+                    assert -Pi <= dy and (Hm - 1) * s + dy < Hi + Pi and -Pi <= dx and (Wm - 1) * s + dx < Wi + Pi, op['name']
+                    xs = ibuf[:, Pi + dy: Pi + dy + (Hm - 1) * s + 1: s, Pi + dx: Pi + dx + (Wm - 1) * s + 1: s,
+                              inp.coff:inp.coff + inp.C]
+                    acc += xs @ wg[t].T
+                acc = acc + torch.from_numpy(op['bias'][g])
+                oy, ox = op['out_off'][g]
+                r = op['res'][g]
+                if r is not None:
+                    rbuf, Pr, Hr, Wr = view(r)
+                    acc = acc + rbuf[:, Pr + oy: Pr + oy + (Hm - 1) * sc + 1: sc, Pr + ox: Pr + ox + (Wm - 1) * sc + 1: sc, r.coff:r.coff + r.C]
+                if op['relu']:
+                    acc = acc.relu()
+                if op['out_nchw']:
+                    outs[op['out_nchw'] - 1] = acc.permute(0, 3, 1, 2).contiguous()
+                else:
+                    o = op['out'][g]
+                    obuf, Po, Ho, Wo = view(o)
+                    obuf[:, Po + oy: Po + oy + (Hm - 1) * sc + 1: sc, Po + ox: Po + ox + (Wm - 1) * sc + 1: sc, o.coff:o.coff + o.C] = rnd(acc)
+        elif op['op'] == 'maxpool':
+            i, o = op['inp'], op['out']
+            ibuf, Pi, Hi, Wi = view(i)
+            obuf, Po, Ho, Wo = view(o)
+            k, s, p = op['k'], op['stride'], op['pad']
+            assert p <= Pi
+            win = ibuf[:, Pi - p: Pi - p + (Ho - 1) * s + k, Pi - p: Pi - p + (Wo - 1) * s + k, i.coff:i.coff + i.C]
+            y = torch.nn.functional.max_pool2d(win.permute(0, 3, 1, 2), k, s)
+            obuf[:, Po:Po + Ho, Po:Po + Wo, o.coff:o.coff + o.C] = y.permute(0, 2, 3, 1)
+        elif op['op'] == 'softmax':
+            zi, zo = op['z_in'], op['z_out']
+            zb, Pz, H, W = view(zi)
+            acc = zb[:, Pz:Pz + H, Pz:Pz + W, zi.coff:zi.coff + zi.C].clone()
+            for u in op['us']:
+                ub, Pu, Hu, Wu = view(u)
+                uu = ub[:, Pu:Pu + H, Pu:Pu + W, u.coff:u.coff + u.C]
+                sm = torch.softmax(uu.reshape(B, H * W, -1), dim=1).reshape(B, H, W, -1)
+                acc = acc + uu * sm
+            ob, Po, _, _ = view(zo)
+            ob[:, Po:Po + H, Po:Po + W, zo.coff:zo.coff + zo.C] = rnd(acc)
+        else:
+            raise AssertionError(op['op'])
+    # borders must still be zero (the kernels rely on it)
+    for t, b in zip(plan.tensors, bufs):
+        P = t['pad']
+        if P:
+            assert float(b[:, :P].abs().max()) == 0 and float(b[:, :, :P].abs().max()) == 0
+            assert float(b[:, -P:].abs().max()) == 0 and float(b[:, :, -P:].abs().max()) == 0
+
+    def fetch(s):
+        t = plan.tensors[s.tid]
+        P = t['pad']
+        return bufs[s.tid][:, P:P + t['H'], P:P + t['W'], s.coff:s.coff + s.C].permute(0, 3, 1, 2).contiguous()
+    return outs, fetch

@@ -1,0 +1,56 @@
+"""CPU: the host-side plan (graph wiring without torch.cat, BN folding, deconv phases, weight
+packing) reproduces the oracle; and fp16 storage keeps logits within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rtm3d_ref
+from rtm3d_amd import plan as plan_mod, weights
+from tests.plan_interp import run_plan
+
+
+@pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
+def test_plan_matches_oracle_fp32(bb):
+    sd = weights.synth_state_dict(bb, 3, 'trained')
+    x = weights.synth_images(2, 64, 128, seed=5)
+    P = plan_mod.build_plan(sd, bb, 2, 64, 128)
+    outs, fetch = run_plan(P, x)
+    dets, logits, st = rtm3d_ref.model_forward(x, sd, bb, return_stages=True)
+    for i in range(4):
+        np.testing.assert_allclose(fetch(P.named['feat%d' % i]).numpy(), st['feats'][i].numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(fetch(P.named['z']).numpy(), st['z'].numpy(), atol=2e-4, rtol=1e-4)
+    for a, b in zip(outs, logits):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-4, rtol=1e-4)
+
+
+def test_plan_fp16_error_budget():
+    """fp16 weights/activations with fp32 accumulation: logit error stays below 0.03 * logit scale."""
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 3, 'trained')
+    x = weights.synth_images(1, 64, 128, seed=5)
+    P = plan_mod.build_plan(sd, bb, 1, 64, 128)
+    outs, _ = run_plan(P, x, half=True)
+    _, logits = rtm3d_ref.model_forward(x, sd, bb)
+    for a, b in zip(outs, logits):
+        err = (a - b).abs().max().item()
+        assert err < 0.03 * max(1.0, b.abs().max().item()), err
+
+
+def test_weight_packing_roundtrip():
+    rng = np.random.default_rng(0)
+    wt = rng.standard_normal((9, 96, 128)).astype(np.float32)
+    packed, cout_pad = plan_mod.pack_mfma_weights(wt, 64)
+    assert cout_pad == 128
+    pk = packed.reshape(2, 9, 2, 64, 8, 8).astype(np.float32)       # nt, tap, q, r, pos, e
+    for (nt, t, q, r, c) in [(0, 0, 0, 0, 0), (1, 4, 1, 13, 5), (0, 8, 1, 63, 7), (1, 2, 0, 31, 3)]:
+        pos = c ^ (r & 7)
+        co = nt * 64 + r
+        want = wt[t, co, q * 64 + c * 8: q * 64 + c * 8 + 8] if co < 96 else np.zeros(8)
+        np.testing.assert_allclose(pk[nt, t, q, r, pos], want.astype(np.float16).astype(np.float32))
+    d = plan_mod.pack_direct_weights(wt[:, :16, :16]).reshape(9, 8, 16, 2)
+    assert d[3, 5, 7, 1] == np.float16(wt[3, 7, 11])
+
+
+def test_state_dict_spec_counts():
+    assert len(weights.state_dict_spec('DLA-34')) == 321
+    assert len(weights.state_dict_spec('RESNET-18')) == 207
