@@ -1,0 +1,268 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes), against the golden
+vectors of the real reference and against the CPU oracle on fresh seeded inputs.
+
+Bars: decode indices / classes bit-exact; decode float outputs bit-exact (same fp32 operation order
+and the ATen sigmoid reproduced); 3D boxes within 1e-4 (north_star); network logits (fp16 storage,
+fp32 accumulation) within 0.03 x logit scale of the fp32 reference, with the stated tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rtm3d_ref, decode3d_ref          # noqa: E402  (the checker)
+import rtm3d_amd                                     # noqa: E402
+from rtm3d_amd import weights, _lib                  # noqa: E402
+from tests.golden.cases import DECODE2D_CASES, decode2d_inputs   # noqa: E402
+from tests.util import load_golden, dets_from_golden, canon_dets, to_np   # noqa: E402
+
+LOGIT_RTOL = 0.03     # fp16 activations/weights, ~45 layers deep: |err| <= 0.03 * max(1, max|logit|)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    _lib.load()
+    return torch.device('cuda', 0)
+
+
+def make_model(bb, sd=None, thresh=0.4, topk=100):
+    cfg = rtm3d_amd.kitti_config(bb)
+    cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES = thresh, topk
+    m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m
+
+
+# ------------------------------------------------------------------------------ 2D decode
+@pytest.mark.parametrize('name', DECODE2D_CASES)
+def test_decode2d_golden_bit_exact(dev, name):
+    g = load_golden('decode2d_cases.npz')
+    th, tk, arrs = decode2d_inputs(name)
+    m = make_model('RESNET-18', None, th, tk)
+    d = m.inference([torch.from_numpy(a).to(dev) for a in arrs])
+    n = g[name + '_det_n']
+    for b in range(len(n)):
+        if n[b] == 0:
+            assert d[0][b] is None
+            continue
+        got = [to_np(x[b]) for x in d]
+        ref = dets_from_golden(g, name + '_det_', b)
+        assert len(got[0]) == n[b]
+        if name == 'plateau':          # order inside a score tie is implementation-defined in the reference
+            got, ref = canon_dets(*got), canon_dets(*ref)
+        for a, r in zip(got, ref):
+            np.testing.assert_array_equal(a, r)
+
+
+def test_decode2d_random_vs_oracle(dev):
+    rng = np.random.Generator(np.random.PCG64(99))
+    for (B, H, W, th, tk) in [(3, 96, 320, 0.4, 100), (2, 40, 72, 0.3, 50), (1, 7, 9, 0.4, 100), (2, 96, 320, 0.05, 256)]:
+        lg = [torch.from_numpy((rng.standard_normal((B, c, H, W)) * s + o).astype(np.float32))
+              for c, s, o in ((3, 1.5, -2.5), (16, 3, 0), (2, 2, 0), (2, 1, 0))]
+        m = make_model('RESNET-18', None, th, tk)
+        d = m.inference([t.to(dev) for t in lg])
+        r = rtm3d_ref.inference(lg, th, tk, 4.0)
+        for b in range(B):
+            if r[0][b] is None:
+                assert d[0][b] is None
+                continue
+            # skip images whose top-(k+1) scores tie (reference order undefined there)
+            sc = r[1][b].numpy()
+            if len(np.unique(sc)) != len(sc):
+                continue
+            for k in range(5):
+                np.testing.assert_array_equal(to_np(d[k][b]), to_np(r[k][b]))
+
+
+def test_decode2d_topk_determinism_with_ties(dev):
+    """All-equal heat map: every pixel is a plateau member; order must be ascending flat index."""
+    H, W = 8, 16
+    lg = [torch.full((1, 3, H, W), 2.0), torch.zeros(1, 16, H, W), torch.zeros(1, 2, H, W), torch.zeros(1, 2, H, W)]
+    m = make_model('RESNET-18', None, 0.4, 100)
+    d = m.inference([t.to(dev) for t in lg])
+    assert len(d[0][0]) == 100
+    x = (d[2][0][:, 0].cpu().numpy() / 4.0 - 0.5).round().astype(int)
+    y = (d[2][0][:, 1].cpu().numpy() / 4.0 - 0.5).round().astype(int)
+    flat = d[0][0].cpu().numpy() * H * W + y * W + x
+    np.testing.assert_array_equal(flat, np.arange(100))
+
+
+# ------------------------------------------------------------------------------ 3D decode
+def test_decode3d_golden(dev):
+    g = load_golden('decode3d_cases.npz')
+    x, fun, nit, st = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
+    kept_ref = g['raw_fun'] < 0.1
+    np.testing.assert_array_equal(fun < 0.1, kept_ref)
+    np.testing.assert_allclose(x[kept_ref], g['raw_x'][kept_ref], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(x, g['raw_x'], rtol=0, atol=1e-4)          # north_star tolerance, incl. rejected objects
+    np.testing.assert_allclose(fun, g['raw_fun'], rtol=1e-5, atol=1e-9)
+    out = rtm3d_amd.model_utils.optim_decode_bbox3d(g['clses'], g['uv'], g['K'], g['dim_ref'].tolist(), g['ref_loc'].tolist())
+    assert out.get_field('class') == g['out_class'].tolist()
+    np.testing.assert_allclose(out.get_field('Ry'), g['out_Ry'], atol=1e-4)
+    np.testing.assert_allclose(out.get_field('dimension'), g['out_dimension'], atol=1e-4)
+    np.testing.assert_allclose(out.get_field('location'), g['out_location'], atol=1e-4)
+    np.testing.assert_array_equal(out.get_field('K'), g['out_K'])
+    e = rtm3d_amd.model_utils.optim_decode_bbox3d(np.zeros((0,), np.int64), np.zeros((0, 8, 2), np.float32), g['K'], g['dim_ref'].tolist(), [0, -0.5, 20])
+    assert e.get_field('dimension').shape == (0, 3) and e.get_field('K').shape == (0, 9) and e.get_field('class') == []
+
+
+def test_decode3d_random_vs_scipy(dev):
+    """Fresh objects: same answer as the SciPy-driven oracle within 1e-4 (kept objects)."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    K = weights.synth_intrinsics()
+    dim_ref = rtm3d_amd.kitti_config().DETECTOR.dim_ref
+    clses, uvs = [], []
+    for i in range(96):
+        cls = int(rng.integers(0, 3))
+        dim = np.array(dim_ref[cls]) * rng.uniform(0.8, 1.25, 3)
+        loc = np.array([rng.uniform(-12, 12), rng.uniform(0.5, 1.6), rng.uniform(6, 55)])
+        uv = decode3d_ref.project_box(dim, loc, rng.uniform(-np.pi, np.pi), K) + rng.choice([0.0, 0.02, 0.1]) * rng.standard_normal((8, 2))
+        clses.append(cls); uvs.append(uv.astype(np.float32))
+    clses, uvs = np.array(clses), np.stack(uvs)
+    x, fun, _, _ = rtm3d_amd.model_utils.solve_boxes(clses, uvs, K, dim_ref, [0, -0.5, 20])
+    _, raw = decode3d_ref.optim_decode_bbox3d(clses, uvs, K, dim_ref, [0, -0.5, 20], return_raw=True)
+    np.testing.assert_array_equal(fun < 0.1, raw['kept'])
+    np.testing.assert_allclose(x[raw['kept']], raw['x'][raw['kept']], rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------ network
+@pytest.mark.parametrize('fname', ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz'])
+def test_forward_logits_vs_reference_golden(dev, fname):
+    g = load_golden(fname)
+    bb = str(g['backbone'])
+    B, H, W = [int(v) for v in g['shape']]
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']))
+    x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
+    m = make_model(bb, sd)
+    (clses, scores, mprojs, verts, boxes), logits = m(x.to(dev))
+    ref0 = g['logits_main_kf']
+    tol = LOGIT_RTOL * max(1.0, np.abs(ref0).max())
+    np.testing.assert_allclose(logits[0].cpu().numpy(), ref0, rtol=0, atol=tol)
+    for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
+        if 'logits_' + name in g:
+            ref = g['logits_' + name]; got = logits[i].cpu().numpy()
+        else:
+            ref = g['logits_%s_s4' % name]; got = logits[i][:, :, ::4, ::4].cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=LOGIT_RTOL * max(1.0, np.abs(ref).max()))
+    # detections: every reference detection whose score is not within the fp16 error of the threshold
+    # must be found at the same (class, y, x), with vertices within 0.25 px (fp16 logits x stride 4)
+    n = g['det_n']
+    for b in range(B):
+        if n[b] == 0:
+            continue
+        rc, rs, rm, rv, _ = dets_from_golden(g, 'det_', b)
+        if clses[b] is None:
+            assert (rs < 0.45).all()
+            continue
+        got = {(int(c), int(mx // 4), int(my // 4)): v for c, (mx, my), v in
+               zip(clses[b].cpu().numpy(), mprojs[b].cpu().numpy(), verts[b].cpu().numpy())}
+        for c, s, mp, v in zip(rc, rs, rm, rv):
+            if s < 0.45:
+                continue
+            key = (int(c), int(mp[0] // 4), int(mp[1] // 4))
+            assert key in got, (key, s)
+            assert np.abs(got[key] - v).max() < 0.25
+
+
+@pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
+def test_forward_stages_vs_oracle(dev, bb):
+    """Fresh seed, batch 3, non-square small input: backbone features, fused map and logits."""
+    sd = weights.synth_state_dict(bb, 11, 'trained', heat_bias=-3.0)
+    x = weights.synth_images(3, 96, 160, seed=77)
+    m = make_model(bb, sd)
+    logits = m.forward_logits(x.to(dev))
+    _, lref, st = rtm3d_ref.model_forward(x, sd, bb, return_stages=True)
+    plan = m._plan_for(3, 96, 160, dev)
+    for i in range(4):
+        got = plan.download(plan.plan.named['feat%d' % i]); ref = st['feats'][i].numpy()
+        assert np.abs(got - ref).max() < LOGIT_RTOL * max(1.0, np.abs(ref).max())
+    got = plan.download(plan.plan.named['z']); ref = st['z'].numpy()
+    assert np.abs(got - ref).max() < LOGIT_RTOL * max(1.0, np.abs(ref).max())
+    for a, b in zip(logits, lref):
+        assert (a.cpu() - b).abs().max().item() < LOGIT_RTOL * max(1.0, b.abs().max().item())
+
+
+def test_pipeline_on_oracle_logits_matches_reference_golden(dev):
+    """Stage parity regime (SURVEY H2 i): decode kernels fed the reference's fp32 logits reproduce the
+    reference's detections bit-exactly and its 3D boxes within 1e-4."""
+    g = load_golden('e2e_dla34_small.npz')
+    lg = [torch.from_numpy(g['logits_' + n]).to(dev) for n in ['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset']]
+    m = make_model('DLA-34')
+    d = m.inference(lg)
+    for b in range(len(g['det_n'])):
+        if g['det_n'][b] == 0:
+            assert d[0][b] is None
+            continue
+        for k, r in enumerate(dets_from_golden(g, 'det_', b)):
+            np.testing.assert_array_equal(to_np(d[k][b]), r)
+    if 'd3_class' in g:
+        out = rtm3d_amd.model_utils.optim_decode_bbox3d(to_np(d[0][0]), to_np(d[3][0]), g['K'], rtm3d_amd.kitti_config().DETECTOR.dim_ref, [0, -0.5, 20])
+        assert out.get_field('class') == g['d3_class'].tolist()
+        if len(g['d3_class']):
+            np.testing.assert_allclose(out.get_field('location'), g['d3_location'], atol=1e-4)
+            np.testing.assert_allclose(out.get_field('dimension'), g['d3_dimension'], atol=1e-4)
+            np.testing.assert_allclose(out.get_field('Ry'), g['d3_Ry'], atol=1e-4)
+
+
+def test_detect3d_pipeline_and_batch_invariance(dev):
+    """Fused device pipeline; images are independent: batch of 4 == four batches of 1 (bit-exact)."""
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5)
+    m = make_model(bb, sd)
+    x = weights.synth_images(4, 64, 128, seed=5).to(dev)
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (4, 1)), device=dev)
+    det, boxes, logits = m.detect3d(x, K)
+    torch.cuda.synchronize()
+    n = det.n.cpu().numpy()
+    for b in range(4):
+        d1, b1, l1 = m.detect3d(x[b:b + 1], K[b:b + 1])
+        assert int(d1.n.item()) == int(n[b])
+        for a, c in zip(logits, l1):
+            assert torch.equal(a[b:b + 1], c)
+        k = int(n[b])
+        assert torch.equal(det.verts[b * 100: b * 100 + k], d1.verts[:k])
+        assert torch.equal(boxes.x[b * 100: b * 100 + k], b1.x[:k])
+    st = boxes.status.cpu().numpy().reshape(4, 100)
+    for b in range(4):
+        assert (st[b, :n[b]] >= 0).all() and (st[b, n[b]:] == -1).all()
+
+
+def test_full_size_round_trip_properties(dev):
+    """BASELINE full size (bs=4 of 384x1280): size-independent properties instead of an oracle run:
+    NMS idempotence/sortedness of the decode and consistency of boxes with their vertices."""
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-6.0)
+    m = make_model(bb, sd)
+    x = weights.synth_images(4, 384, 1280, seed=1234).to(dev)
+    (clses, scores, mprojs, verts, boxes), logits = m(x)
+    assert logits[0].shape == (4, 3, 96, 320) and logits[1].shape == (4, 16, 96, 320)
+    for b in range(4):
+        if clses[b] is None:
+            continue
+        s = scores[b].cpu().numpy()
+        assert (np.diff(s) <= 0).all() and (s > 0.4).all() and len(s) <= 100       # sorted, thresholded, capped
+        v = verts[b].cpu().numpy(); bx = boxes[b].cpu().numpy()
+        np.testing.assert_array_equal(bx[:, :2], v.min(1)); np.testing.assert_array_equal(bx[:, 2:], v.max(1))
+        # every detection is a strict 3x3 local maximum of its class plane
+        hm = torch.sigmoid(logits[0][b]).cpu()
+        for c, (mx, my) in zip(clses[b].cpu().numpy(), mprojs[b].cpu().numpy()):
+            xx, yy = int(mx // 4), int(my // 4)
+            win = hm[c, max(0, yy - 1):yy + 2, max(0, xx - 1):xx + 2]
+            assert float(win.max()) == float(hm[c, yy, xx])
+
+
+def test_errors_are_loud(dev):
+    m = make_model('DLA-34')
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64))                    # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 65, 64, device=dev))        # not a multiple of 32
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({'bogus': torch.zeros(1)})
+    lib = _lib.load()
+    assert lib.rtm3d_decode2d(None, None, None, None, 1, 3, 8, 8, ctypes.c_float(0.4), 100, ctypes.c_float(4.0), None, None, None, None, None, None, None) != 0
+    assert b'null' in lib.rtm3d_last_error()
