@@ -75,6 +75,7 @@ struct SoftmaxKArgs {
 
 // kernel launchers (each returns hipGetLastError())
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
+hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, hipStream_t s);
 hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStream_t s);
 bool conv_direct_supported(int cin, int cout, int ntaps);
 hipError_t launch_stem(const StemKArgs& a, int ksize, int cout, hipStream_t s);

@@ -4,6 +4,7 @@
 // kernel only needs enough lanes in flight: 64-lane workgroups, objects spread over the CUs.
 #include "common.h"
 #include "lbfgsb.h"
+#include "lbfgsb_wave.h"
 #include "../../include/rtm3d_hip.h"
 
 // slot mode (n_per_image != nullptr): object i lives in slot (image = i / topk, rank = i % topk) of
@@ -39,6 +40,41 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
     status[i] = st;
 }
 
+// One wavefront per object (lbfgsb_wave.h): the production kernel.  blockIdx.x = object / slot.
+__global__ __launch_bounds__(64) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
+                                                           const float* __restrict__ verts, const double* __restrict__ K,
+                                                           const double* __restrict__ dim_ref, int ncls,
+                                                           const double* __restrict__ ref_loc, double* __restrict__ x_out,
+                                                           double* __restrict__ f_out, int32_t* __restrict__ nit,
+                                                           int32_t* __restrict__ status,
+                                                           const int32_t* __restrict__ n_per_image, int topk) {
+    __shared__ LbWaveMem mem;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= N) return;
+    int ki = i;
+    if (n_per_image) {
+        ki = i / topk;
+        if (i - ki * topk >= n_per_image[ki]) { if (lane == 0) status[i] = -1; return; }
+    }
+    LbWaveK Kk;
+    Kk.k00 = K[ki * 9 + 0]; Kk.k02 = K[ki * 9 + 2]; Kk.k11 = K[ki * 9 + 4]; Kk.k12 = K[ki * 9 + 5];
+    int c = (int)cls[i];
+    c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+    const double* dim = dim_ref + c * 3;
+    if (lane < 16) mem.uv[lane] = (double)verts[(size_t)i * 16 + lane];
+    if (lane == 0) {
+        mem.x[0] = 0.0; mem.x[1] = 1.0; mem.x[2] = dim[2]; mem.x[3] = dim[0]; mem.x[4] = dim[1];
+        mem.x[5] = ref_loc[0]; mem.x[6] = ref_loc[1]; mem.x[7] = ref_loc[2];
+    }
+    __syncthreads();
+    double f;
+    int it;
+    const int st = lbw_minimize(&mem, Kk, &f, &it, lane, 15000, 15000);
+    __syncthreads();
+    if (lane < 8) x_out[(size_t)i * 8 + lane] = mem.x[lane];
+    if (lane == 0) { f_out[i] = f; nit[i] = it; status[i] = st; }
+}
+
 extern void rt_set_error(const char* fmt, ...);
 
 extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
@@ -49,7 +85,7 @@ extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const f
     if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
         rt_set_error("decode3d: null pointer"); return 1;
     }
-    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+    hipLaunchKernelGGL(decode3d_wave_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
                        d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d launch: %s", hipGetErrorString(e)); return 1; }
@@ -65,9 +101,21 @@ extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t
         rt_set_error("decode3d_slots: null pointer"); return 1;
     }
     const int N = B * topk;
-    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+    hipLaunchKernelGGL(decode3d_wave_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
                        d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d_slots launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// Same problem on the one-lane-per-object kernel (scalar lbfgsb.h): cross-check of the wave kernel.
+extern "C" int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                                     const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
+                                     double* d_fun, int32_t* d_nit, int32_t* d_status) {
+    if (N <= 0 || ncls <= 0) { rt_set_error("decode3d_scalar: bad sizes"); return 1; }
+    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+                       d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode3d_scalar launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
 }

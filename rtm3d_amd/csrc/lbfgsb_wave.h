@@ -1,0 +1,413 @@
+// Wave-cooperative form of lbfgsb.h: ONE 64-lane wavefront solves ONE object.
+//
+// Same algorithm, same fp64 arithmetic in the same order as the scalar version (every individual
+// sum still runs sequentially in index order inside one lane), but
+//   - all limited-memory matrices live in LDS (11.5 KB per object) instead of per-lane scratch,
+//   - independent matrix entries / right-hand sides / vector components are spread over lanes
+//     (formk rows and columns, the 55 entries of T and of the (2,2) block, the col right-hand sides
+//     of the triangular solve, the 8x8 corner x component terms of the gradient),
+//   - triangular solves and Cholesky factorisations advance one pivot per step with the lane-owned
+//     partial sums updated in pivot order (identical rounding to the dot-product form),
+//   - scalar control (line search state, convergence tests) is computed redundantly by every lane
+//     from LDS broadcasts, so control flow stays wave-uniform without any cross-lane traffic.
+// The workgroup is a single wave, so __syncthreads() is only an LDS ordering fence.
+#pragma once
+#include "lbfgsb.h"
+
+#if defined(__HIPCC__)
+#pragma clang fp contract(off)
+
+#define WSYNC() __syncthreads()
+
+struct LbWaveMem {
+    double ws[LB_N * LB_M], wy[LB_N * LB_M];
+    double sy[LB_M * LB_M], ss[LB_M * LB_M], wt[LB_M * LB_M];
+    double wn[LB_M2 * LB_M2], wn1[LB_M2 * LB_M2];
+    double x[LB_N], z[LB_N], r[LB_N], d[LB_N], t[LB_N], g[LB_N], wv[LB_M2];
+    double terms[64], fterms[16], bc[2];
+    double uv[16];
+};
+#define VWS_(i, j) w->ws[((j)-1) * LB_N + (i)-1]
+#define VWY_(i, j) w->wy[((j)-1) * LB_N + (i)-1]
+#define VSY_(i, j) w->sy[((j)-1) * LB_M + (i)-1]
+#define VSS_(i, j) w->ss[((j)-1) * LB_M + (i)-1]
+#define VWT_(i, j) w->wt[((j)-1) * LB_M + (i)-1]
+#define VWN_(i, j) w->wn[((j)-1) * LB_M2 + (i)-1]
+#define VWN1_(i, j) w->wn1[((j)-1) * LB_M2 + (i)-1]
+
+struct LbWaveK { double k00, k02, k11, k12; };
+
+// f (returned, identical in every lane) and g (-> w->g) at w->x.
+__device__ static inline double lbw_fg(LbWaveMem* w, const LbWaveK& K, int lane) {
+    const int c = lane >> 3, i = lane & 7;
+    double c0, c1, c2;
+    lb_corner(c, &c0, &c1, &c2);
+    const double x0 = w->x[0], x1 = w->x[1], x2 = w->x[2], x3 = w->x[3], x4 = w->x[4], x5 = w->x[5], x6 = w->x[6], x7 = w->x[7];
+    const double xc = c0 * x2 * x1 + c2 * x4 * x0 + x5;
+    const double yc = c1 * x3 + x6;
+    const double zc = (-c0) * x2 * x0 + c2 * x4 * x1 + x7;
+    const double u = w->uv[2 * c], v = w->uv[2 * c + 1];
+    if (i == 0) {
+        const double ex = xc * K.k00 / (zc + 1e-4) + K.k02 - u;
+        const double ey = yc * K.k11 / (zc + 1e-4) + K.k12 - v;
+        w->fterms[2 * c] = ex * ex;
+        w->fterms[2 * c + 1] = ey * ey;
+    }
+    const double dex = (xc * K.k00 / (zc + 1e-6) + K.k02 - u) * 2;
+    const double dey = (yc * K.k11 / (zc + 1e-6) + K.k12 - v) * 2;
+    double dx, dy, dz;
+    switch (i) {
+        case 0: dx = c2 * x4; dy = 0; dz = (-c0) * x2; break;
+        case 1: dx = c0 * x2; dy = 0; dz = c2 * x4; break;
+        case 2: dx = c0 * x1; dy = 0; dz = (-c0) * x0; break;
+        case 3: dx = 0; dy = c1; dz = 0; break;
+        case 4: dx = c2 * x0; dy = 0; dz = c2 * x1; break;
+        case 5: dx = 1; dy = 0; dz = 0; break;
+        case 6: dx = 0; dy = 1; dz = 0; break;
+        default: dx = 0; dy = 0; dz = 1; break;
+    }
+    const double den = zc * zc + 1e-6;
+    const double gx = K.k00 * (dx * zc - dz * xc) / den;
+    const double gy = K.k11 * (dy * zc - dz * yc) / den;
+    w->terms[lane] = dex * gx + dey * gy;
+    WSYNC();
+    if (lane < 8) {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += w->terms[k * 8 + lane];
+        w->g[lane] = s;
+    }
+    double f = 0.0;
+    for (int k = 0; k < 16; ++k) f += w->fterms[k];
+    WSYNC();
+    return f;
+}
+
+__device__ static inline double lbw_dot8(const double* a, const double* b) {
+    double s = 0.0;
+    for (int i = 0; i < LB_N; ++i) s += a[i] * b[i];
+    return s;
+}
+
+// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block, in place.
+__device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < j; ++k) s += a[j * lda + k] * a[j * lda + k];
+        double ajj = a[j * lda + j] - s;
+        if (!(ajj > 0.0)) return j + 1;                 // uniform
+        ajj = sqrt(ajj);
+        const double rinv = 1.0 / ajj;
+        const int i = j + 1 + lane;
+        double v = 0.0;
+        if (i < n) {
+            double dot = 0.0;
+            for (int k = 0; k < j; ++k) dot += a[j * lda + k] * a[i * lda + k];
+            v = (a[i * lda + j] - dot) * rinv;
+        }
+        WSYNC();                                        // everyone has read column j / a(j,j)
+        if (i < n) a[i * lda + j] = v;
+        if (lane == 0) a[j * lda + j] = ajj;
+        WSYNC();
+    }
+    return 0;
+}
+
+// U' x = b, single right-hand side in LDS (length n <= 64): lane j owns b[j] and its partial sum.
+__device__ static inline int lbw_trsv_ut(const double* a, int lda, int n, double* b, double* bc, int lane) {
+    double dot = 0.0;
+    double bj = lane < n ? b[lane] : 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double akk = a[k * lda + k];
+        if (akk == 0.0) return k + 1;
+        if (lane == k) { bj = (bj - dot) / akk; bc[0] = bj; }
+        WSYNC();
+        const double bk = bc[0];
+        if (lane > k && lane < n) dot += a[lane * lda + k] * bk;
+        WSYNC();
+    }
+    if (lane < n) b[lane] = bj;
+    WSYNC();
+    return 0;
+}
+// U x = b (column-oriented back substitution, same update order as the scalar version)
+__device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double* b, double* bc, int lane) {
+    double bk = lane < n ? b[lane] : 0.0;
+    for (int j = n - 1; j >= 0; --j) {
+        const double ajj = a[j * lda + j];
+        if (ajj == 0.0) return j + 1;
+        if (lane == j) { bk = bk / ajj; bc[0] = bk; }
+        WSYNC();
+        const double tmp = -bc[0];
+        if (lane < j) bk += tmp * a[j * lda + lane];
+        WSYNC();
+    }
+    if (lane < n) b[lane] = bk;
+    WSYNC();
+    return 0;
+}
+
+__device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, int col, int head, int lane) {
+    const int m = LB_M, n = LB_N;
+    if (iupdat > m) {
+        // shift the old part of WN1 one step up-left; two-phase (read all, then write all)
+        double v[3]; int dst[3]; int cnt = 0;
+        int e = 0;
+        for (int jy = 1; jy <= m - 1; ++jy) {
+            const int js = m + jy;
+            for (int k = 0; k < m - jy; ++k, ++e)
+                if ((e & 63) == lane) { v[cnt] = VWN1_(jy + 1 + k, jy + 1); dst[cnt++] = (jy - 1) * LB_M2 + (jy + k - 1); }
+            for (int k = 0; k < m - jy; ++k, ++e)
+                if ((e & 63) == lane) { v[cnt] = VWN1_(js + 1 + k, js + 1); dst[cnt++] = (js - 1) * LB_M2 + (js + k - 1); }
+            for (int k = 0; k < m - 1; ++k, ++e)
+                if ((e & 63) == lane) { v[cnt] = VWN1_(m + 2 + k, jy + 1); dst[cnt++] = (jy - 1) * LB_M2 + (m + 1 + k - 1); }
+        }
+        WSYNC();
+        for (int q = 0; q < cnt; ++q) w->wn1[dst[q]] = v[q];
+        WSYNC();
+    }
+    {
+        int ipntr = head + col - 1;
+        if (ipntr > m) ipntr -= m;
+        const int jy = lane + 1;
+        if (jy <= col) {
+            const int jpntr = (head + jy - 2) % m + 1;
+            double temp1 = 0.0;
+            for (int k = 1; k <= n; ++k) temp1 += VWY_(k, ipntr) * VWY_(k, jpntr);
+            VWN1_(col, jy) = temp1;
+            VWN1_(m + col, m + jy) = 0.0;
+            VWN1_(m + col, jy) = 0.0;
+        }
+        WSYNC();
+        const int i = lane + 1;
+        if (i <= col) {
+            const int ip = (head + i - 2) % m + 1;
+            double temp3 = 0.0;
+            for (int k = 1; k <= n; ++k) temp3 += VWS_(k, ip) * VWY_(k, ipntr);
+            VWN1_(m + i, col) = temp3;
+        }
+        WSYNC();
+    }
+    for (int e = lane; e < col * col; e += 64) {
+        const int iy = e / col + 1, jy = e % col + 1;
+        const int is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
+        if (jy <= iy) {
+            double v = VWN1_(iy, jy) / theta;
+            if (jy == iy) v = v + VSY_(iy, iy);
+            VWN_(jy, iy) = v;
+            VWN_(js, is) = VWN1_(is1, js1) * theta;
+        }
+        VWN_(jy, is) = (jy < iy) ? -VWN1_(is1, jy) : VWN1_(is1, jy);
+    }
+    WSYNC();
+    if (lbw_potrf(w->wn, LB_M2, col, lane) != 0) return -1;
+    const int col2 = 2 * col;
+    {   // L^-1 (-L_a' + R_z'): one right-hand side (column) per lane
+        int bad = 0;
+        if (lane < col) {
+            double* b = &VWN_(1, col + 1 + lane);
+            for (int j = 0; j < col; ++j) {
+                if (w->wn[j * LB_M2 + j] == 0.0) { bad = 1; break; }
+                double dot = 0.0;
+                for (int k = 0; k < j; ++k) dot += w->wn[j * LB_M2 + k] * b[k];
+                b[j] = (b[j] - dot) / w->wn[j * LB_M2 + j];
+            }
+        }
+        if (__any(bad)) return -1;
+        WSYNC();
+    }
+    {   // (2,2) block += (L^-1 ...)'(L^-1 ...), upper triangle: one entry per lane (<= 55)
+        int j = 0;
+        while ((j + 1) * (j + 2) / 2 <= lane) ++j;
+        const int i = lane - j * (j + 1) / 2;
+        if (j < col) {
+            const int is = col + 1 + i, js = col + 1 + j;
+            double dot = 0.0;
+            for (int k = 1; k <= col; ++k) dot += VWN_(k, is) * VWN_(k, js);
+            VWN_(is, js) = VWN_(is, js) + dot;
+        }
+        WSYNC();
+    }
+    if (lbw_potrf(&VWN_(col + 1, col + 1), LB_M2, col, lane) != 0) return -2;
+    (void)col2;
+    return 0;
+}
+
+__device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int head, int lane) {
+    const int m = LB_M, n = LB_N;
+    const int col2 = 2 * col;
+    if (lane < col2) {
+        const int i = (lane < col ? lane : lane - col) + 1;
+        const int pointr = (head + i - 2) % m + 1;
+        double tmp = 0.0;
+        if (lane < col) { for (int j = 1; j <= n; ++j) tmp += VWY_(j, pointr) * w->r[j - 1]; w->wv[lane] = tmp; }
+        else { for (int j = 1; j <= n; ++j) tmp += VWS_(j, pointr) * w->r[j - 1]; w->wv[lane] = theta * tmp; }
+    }
+    WSYNC();
+    if (lbw_trsv_ut(w->wn, LB_M2, col2, w->wv, w->bc, lane) != 0) return 1;
+    if (lane < col) w->wv[lane] = -w->wv[lane];
+    WSYNC();
+    if (lbw_trsv_un(w->wn, LB_M2, col2, w->wv, w->bc, lane) != 0) return 1;
+    if (lane < n) {
+        double di = w->r[lane];
+        int pointr = head;
+        for (int jy = 1; jy <= col; ++jy) {
+            di = di + VWY_(lane + 1, pointr) * w->wv[jy - 1] / theta + VWS_(lane + 1, pointr) * w->wv[col + jy - 1];
+            pointr = pointr % m + 1;
+        }
+        di = (1.0 / theta) * di;
+        w->r[lane] = di;
+        w->z[lane] = w->z[lane] + di;
+    }
+    WSYNC();
+    return 0;
+}
+
+__device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, int* col, int* head, double* theta,
+                                         double rr, double dr, double stp, double dtd, int lane) {
+    const int m = LB_M, n = LB_N;
+    if (iupdat <= m) {
+        *col = iupdat;
+        *itail = (*head + iupdat - 2) % m + 1;
+    } else {
+        *itail = *itail % m + 1;
+        *head = *head % m + 1;
+    }
+    if (lane < n) { VWS_(lane + 1, *itail) = w->d[lane]; VWY_(lane + 1, *itail) = w->r[lane]; }
+    *theta = rr / dr;
+    if (iupdat > m) {
+        double v[2]; int dst[2], which[2]; int cnt = 0, e = 0;
+        for (int j = 1; j <= *col - 1; ++j) {
+            for (int k = 0; k < j; ++k, ++e)
+                if ((e & 63) == lane) { v[cnt] = VSS_(2 + k, j + 1); dst[cnt] = (j - 1) * LB_M + k; which[cnt++] = 0; }
+            for (int k = 0; k < *col - j; ++k, ++e)
+                if ((e & 63) == lane) { v[cnt] = VSY_(j + 1 + k, j + 1); dst[cnt] = (j - 1) * LB_M + (j + k - 1); which[cnt++] = 1; }
+        }
+        WSYNC();
+        for (int q = 0; q < cnt; ++q) { if (which[q]) w->sy[dst[q]] = v[q]; else w->ss[dst[q]] = v[q]; }
+    }
+    WSYNC();
+    const int j = lane + 1;
+    if (j <= *col - 1) {
+        const int pointr = (*head + j - 2) % m + 1;
+        VSY_(*col, j) = lbw_dot8(w->d, &VWY_(1, pointr));
+        VSS_(j, *col) = lbw_dot8(&VWS_(1, pointr), w->d);
+    }
+    if (lane == 0) {
+        VSS_(*col, *col) = (stp == 1.0) ? dtd : stp * stp * dtd;
+        VSY_(*col, *col) = dr;
+    }
+    WSYNC();
+}
+
+__device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int lane) {
+    int j0 = 0;
+    while ((j0 + 1) * (j0 + 2) / 2 <= lane) ++j0;
+    const int i = lane - j0 * (j0 + 1) / 2 + 1, j = j0 + 1;      // 1 <= i <= j
+    if (j <= col) {
+        if (i == 1) VWT_(1, j) = theta * VSS_(1, j);
+        else {
+            double ddum = 0.0;
+            for (int k = 1; k <= i - 1; ++k) ddum = ddum + VSY_(i, k) * VSY_(j, k) / VSY_(k, k);
+            VWT_(i, j) = ddum + theta * VSS_(i, j);
+        }
+    }
+    WSYNC();
+    return lbw_potrf(w->wt, LB_M, col, lane) != 0 ? -3 : 0;
+}
+
+// Driver: identical control flow to lb_minimize (lbfgsb.h).  w->x holds x0 on entry, the result on exit.
+__device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double* f_out, int* nit_out, int lane,
+                                          int maxiter, int maxfun) {
+    const int n = LB_N, maxls = 20;
+    const double epsmch = 2.220446049250313e-16, factr = 1e7, pgtol = 1e-5;
+    const double ftol = 1e-3, gtol = 0.9, xtol = 0.1, big = 1e10;
+    const double tol = factr * epsmch;
+    int col = 0, head = 1, itail = 0, iupdat = 0, updatd = 0, iter = 0, nfgv = 0, info;
+    double theta = 1.0, f, fold = 0.0, gd = 0.0, gdold = 0.0, stp = 0.0, dnorm = 0.0, dtd = 0.0, sbgnrm;
+    LbSearch S;
+
+    f = lbw_fg(w, K, lane); nfgv = 1;
+    sbgnrm = 0.0;
+    for (int i = 0; i < n; ++i) sbgnrm = fmax(sbgnrm, fabs(w->g[i]));
+    if (sbgnrm <= pgtol) { *f_out = f; *nit_out = 0; return 0; }
+
+    for (;;) {
+        if (col == 0) {
+            if (lane < n) w->z[lane] = w->x[lane] + 1.0 * (-w->g[lane]);
+            WSYNC();
+        } else {
+            if (lane < n) { w->z[lane] = w->x[lane]; w->r[lane] = -w->g[lane]; }
+            WSYNC();
+            info = 0;
+            if (updatd) info = lbw_formk(w, iupdat, theta, col, head, lane);
+            if (info == 0) info = lbw_subsm(w, theta, col, head, lane);
+            if (info != 0) {
+                col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0;
+                WSYNC();
+                continue;
+            }
+        }
+        if (lane < n) { w->d[lane] = w->z[lane] - w->x[lane]; w->t[lane] = w->x[lane]; w->r[lane] = w->g[lane]; }
+        WSYNC();
+        dtd = lbw_dot8(w->d, w->d);
+        dnorm = sqrt(dtd);
+        const double stpmx = big;
+        stp = (iter == 0) ? fmin(1.0 / dnorm, stpmx) : 1.0;
+        fold = f;
+        int ifun = 0, iback = 0, ls_fail = 0, start = 1;
+        info = 0;
+        for (;;) {
+            gd = lbw_dot8(w->g, w->d);
+            if (ifun == 0) {
+                gdold = gd;
+                if (gd >= 0.0) { info = -4; break; }
+            }
+            const int task = lb_dcsrch(f, gd, &stp, ftol, gtol, xtol, 0.0, stpmx, start, &S);
+            start = 0;
+            if (task == LS_ERROR) { info = -4; break; }
+            if (task == LS_CONV || task == LS_WARN) break;
+            ifun += 1; nfgv += 1; iback = ifun - 1;
+            WSYNC();
+            if (lane < n) w->x[lane] = (stp == 1.0) ? w->z[lane] : stp * w->d[lane] + w->t[lane];
+            WSYNC();
+            if (iback >= maxls) { ls_fail = 1; break; }
+            f = lbw_fg(w, K, lane);
+        }
+        if (info != 0 || ls_fail) {
+            WSYNC();
+            if (lane < n) { w->x[lane] = w->t[lane]; w->g[lane] = w->r[lane]; }
+            WSYNC();
+            f = fold;
+            if (col == 0) { *f_out = f; *nit_out = iter; return 2; }
+            col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0;
+            continue;
+        }
+        iter += 1;
+        sbgnrm = 0.0;
+        for (int i = 0; i < n; ++i) sbgnrm = fmax(sbgnrm, fabs(w->g[i]));
+        if (iter >= maxiter || nfgv > maxfun) { *f_out = f; *nit_out = iter; return 1; }
+        if (sbgnrm <= pgtol) break;
+        const double ddum0 = lb_max3(fabs(fold), fabs(f), 1.0);
+        if ((fold - f) <= tol * ddum0) break;
+        WSYNC();
+        if (lane < n) w->r[lane] = w->g[lane] - w->r[lane];
+        WSYNC();
+        const double rr = lbw_dot8(w->r, w->r);
+        double dr, ddum;
+        if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
+        else {
+            dr = (gd - gdold) * stp;
+            WSYNC();
+            if (lane < n) w->d[lane] = stp * w->d[lane];
+            WSYNC();
+            ddum = -gdold * stp;
+        }
+        if (dr <= epsmch * ddum) { updatd = 0; continue; }
+        updatd = 1; iupdat += 1;
+        lbw_matupd(w, &itail, iupdat, &col, &head, &theta, rr, dr, stp, dtd, lane);
+        if (lbw_formt(w, col, theta, lane) != 0) { col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0; }
+    }
+    *f_out = f; *nit_out = iter;
+    return 0;
+}
+#endif  // __HIPCC__

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_DIRECT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -224,7 +224,17 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     const double M = (double)a.M;
     op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
     op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0);
-    if (d->kernel == 0) {
+    if (d->kernel == 2) {
+        if (d->cin % 64 || d->cout % 256 || d->out_nchw_f32) RT_FAIL("op_conv(mfma256): needs cin %% 64 == 0, cout %% 256 == 0, NHWC output (cin=%d cout=%d)", d->cin, d->cout);
+        a.cpt = d->cin / 64; a.ksteps = d->ntaps * a.cpt;
+        a.MT = (a.M + 255) / 256; a.NT = d->cout / 256;
+        const size_t per_group = (size_t)d->cout * a.ksteps * 64;
+        if (wbytes != per_group * d->groups * sizeof(f16)) RT_FAIL("op_conv(mfma256): packed weight blob has %zu bytes, expected %zu", wbytes, per_group * d->groups * sizeof(f16));
+        if (bbytes != (size_t)d->cout * d->groups * sizeof(float)) RT_FAIL("op_conv(mfma256): bias blob size mismatch");
+        for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = d->cout * g; }
+        op.kind = OP_CONV_MFMA256; op.bn_tile = 256;
+        op.name = d->ntaps == 1 ? "conv1x1_mfma256" : (d->ntaps == 4 ? "deconv4x4_phase_mfma256" : "conv3x3_mfma256");
+    } else if (d->kernel == 0) {
         const int BN = d->bn_tile;
         if (BN != 16 && BN != 32 && BN != 64 && BN != 128) RT_FAIL("op_conv: bn_tile must be 16/32/64/128");
         if (d->cin % 64) RT_FAIL("op_conv(mfma): cin=%d is not a multiple of 64", d->cin);
@@ -316,6 +326,7 @@ static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_ou
             e = launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
             break;
         }
+        case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, s); break;
         case OP_CONV_DIRECT: e = launch_conv_direct(op.conv, 0, op.groups, s); break;
         case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
         case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;

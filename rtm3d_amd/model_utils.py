@@ -66,7 +66,7 @@ def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0)):
     return out
 
 
-def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None):
+def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_kernel=False):
     """Raw solver results for N objects: (x (N,8), fun (N,), nit (N,), status (N,)) as numpy."""
     lib = _lib.load()
     dev = _device(device)
@@ -84,7 +84,8 @@ def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None):
         d_dim = torch.as_tensor(np.asarray(ref_dim, np.float64), device=dev).contiguous()
         d_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev).contiguous()
         out = Boxes3D(N, dev)
-        _lib.check(lib.rtm3d_decode3d(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), N, d_cls.data_ptr(),
+        fn = lib.rtm3d_decode3d_scalar if scalar_kernel else lib.rtm3d_decode3d
+        _lib.check(fn(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), N, d_cls.data_ptr(),
                                       d_uv.data_ptr(), d_K.data_ptr(), d_dim.data_ptr(), int(d_dim.shape[0]), d_loc.data_ptr(),
                                       out.x.data_ptr(), out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode3d')
         return out.x.cpu().numpy(), out.fun.cpu().numpy(), out.nit.cpu().numpy(), out.status.cpu().numpy()

@@ -326,6 +326,16 @@ def choose_bn_tile(cout, M):
     return 64
 
 
+def choose_variant(cin, cout, M, groups, out_nchw):
+    """2 = 256x256-tile 8-wave kernel (conv_mfma256.hip) when the layer has enough tiles to fill the
+    chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 1 = direct (small cin)."""
+    if cin % 64:
+        return 1
+    if not out_nchw and cout % 256 == 0 and ((M + 255) // 256) * (cout // 256) * groups >= 512:
+        return 2
+    return 0
+
+
 def pack_mfma_weights(wt, bn):
     """wt: (taps, cout, cin) fp32 -> fp16 [ntile][kstep=(tap, cin/64)][bn rows][8 chunks][8] with the
     LDS bank swizzle (chunk ^= row & 7) baked in (see conv_mfma.hip)."""
@@ -397,8 +407,15 @@ class RealizedPlan(object):
         d.out_nchw_f32 = op['out_nchw']
         d.out_H, d.out_W = op['out_hw']
         M = self.plan.B * op['Hm'] * op['Wm']
-        if op['cin'] % 64 == 0:
-            bn = choose_bn_tile(op['cout'], M)
+        variant = op.get('variant')
+        if variant is None:
+            variant = choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
+        if variant == 2:
+            packed = [pack_mfma_weights(op['w'][g], 256)[0] for g in range(G)]
+            d.kernel, d.bn_tile = 2, 256
+            d.w_blob, d.bias_blob = self._blob(np.concatenate(packed)), self._blob(np.ascontiguousarray(op['bias'], np.float32).reshape(-1))
+        elif op['cin'] % 64 == 0:
+            bn = op.get('bn_tile') or choose_bn_tile(op['cout'], M)
             packed, biases = [], []
             for g in range(G):
                 pw, cout_pad = pack_mfma_weights(op['w'][g], bn)

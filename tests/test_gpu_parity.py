@@ -110,6 +110,16 @@ def test_decode3d_golden(dev):
     assert e.get_field('dimension').shape == (0, 3) and e.get_field('K').shape == (0, 9) and e.get_field('class') == []
 
 
+def test_decode3d_wave_kernel_equals_scalar_kernel(dev):
+    """The wave-cooperative solver performs the same fp64 operations in the same order as the
+    one-lane-per-object form of lbfgsb.h: results are bit-identical."""
+    g = load_golden('decode3d_cases.npz')
+    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
+    b = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], scalar_kernel=True)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
 def test_decode3d_random_vs_scipy(dev):
     """Fresh objects: same answer as the SciPy-driven oracle within 1e-4 (kept objects)."""
     rng = np.random.Generator(np.random.PCG64(2024))
