@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
 
@@ -102,7 +103,13 @@ def main():
     K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
     topk = int(cfg.DETECTOR.TOPK_CANDIDATES)
 
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    pipe = Detect3DPipeline(model, B, dev, gather=True) if not args.serial else None
+
     def step():
+        if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
+            i = pipe.submit(x, K)
+            return i, pipe.det[i % pipe.depth]
         det, boxes, _ = model.detect3d(x, K)
         rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, topk, boxes)
         return rdist.all_gather_records(rec), det
@@ -122,6 +129,8 @@ def main():
     plan.probe_set(dom)                         # reset the probe ring: only timed steps are averaged
 
     def fence():
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -139,6 +148,8 @@ def main():
         dt = float(t.item())
     dom_ms, dom_n = plan.probe_read()
     n_det = det.n.sum().item()
+    if pipe is not None:
+        rec = pipe.results(rec)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

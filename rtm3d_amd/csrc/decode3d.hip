@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 }
 
 // One wavefront per object (lbfgsb_wave.h): the production kernel.  blockIdx.x = object / slot.
-__global__ __launch_bounds__(64) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
+__global__ __launch_bounds__(64, 4) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
                                                            const double* __restrict__ dim_ref, int ncls,
                                                            const double* __restrict__ ref_loc, double* __restrict__ x_out,

@@ -42,22 +42,24 @@ class Boxes3D(object):
 
     @property
     def dimension(self):               # :302  (h, w, l)
-        return self.x[:, [3, 4, 2]]
+        return torch.cat([self.x[:, 3:5], self.x[:, 2:3]], dim=1)   # no host-side index tensor (would sync)
 
     @property
     def location(self):                # :303
         return self.x[:, 5:8]
 
 
-def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0)):
+def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0), out=None):
     """Stream-ordered 3D decode of the slots produced by Model.decode2d (no host sync)."""
     lib = _lib.load()
     dev = det.n.device
     B, topk = det.n.shape[0], det.topk
     K = torch.as_tensor(K_per_image, dtype=torch.float64, device=dev).reshape(B, 9).contiguous()
-    dim = torch.as_tensor(np.asarray(dim_ref, np.float64), device=dev).contiguous()
-    loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev).contiguous()
-    out = Boxes3D(B * topk, dev)
+    dim = dim_ref if isinstance(dim_ref, torch.Tensor) else torch.as_tensor(np.asarray(dim_ref, np.float64), device=dev)
+    loc = ref_loc if isinstance(ref_loc, torch.Tensor) else torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev)
+    dim, loc = dim.to(dev, torch.float64).contiguous(), loc.to(dev, torch.float64).contiguous()
+    if out is None:
+        out = Boxes3D(B * topk, dev)
     with torch.cuda.device(dev):
         _lib.check(lib.rtm3d_decode3d_slots(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, topk,
                                             det.n.data_ptr(), det.cls.data_ptr(), det.verts.data_ptr(), K.data_ptr(),

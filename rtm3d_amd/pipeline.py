@@ -1,0 +1,69 @@
+"""Stream-level pipelining of the hot path on one GPU.
+
+The 3D decode is latency-bound fp64 work on a few hundred wavefronts; the network is MFMA/HBM-bound
+work on thousands of workgroups.  Running them on two HIP streams lets the decode of batch i fill
+idle issue slots while batch i+1's backbone is already running:
+
+    main stream : forward(i) -> decode2d(i) -> [event A_i] ............. forward(i+1) -> ...
+    side stream :                               wait A_i -> decode3d(i) -> pack -> all-gather(i) -> [event B_i]
+
+Outputs are double-buffered (slot i % 2); the main stream waits for B_{i-2} before decode2d
+overwrites slot i % 2.  No host synchronisation inside; `results(i)` hands out the records of a
+finished step after waiting on B_i.
+"""
+import numpy as np
+import torch
+
+from .model import Detections
+from .model_utils import Boxes3D, decode3d_slots
+from . import distributed as rdist
+
+
+class Detect3DPipeline(object):
+    def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=2):
+        self.model, self.B, self.dev = model, batch, torch.device(device)
+        self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
+        dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
+        # device-resident constants: a pageable host->device copy inside submit() would block the host
+        self.dim_ref = torch.as_tensor(np.asarray(dim_ref, np.float64), device=self.dev)
+        self.ref_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=self.dev)
+        self.gather = gather
+        self.depth = depth
+        with torch.cuda.device(self.dev):
+            self.side = torch.cuda.Stream(device=self.dev, priority=-1)   # high priority: few, long, latency-bound waves
+            self.det = [Detections(batch, self.topk, self.dev) for _ in range(depth)]
+            self.boxes = [Boxes3D(batch * self.topk, self.dev) for _ in range(depth)]
+            self.ev_a = [torch.cuda.Event() for _ in range(depth)]
+            self.ev_b = [torch.cuda.Event() for _ in range(depth)]
+        self.rec = [None] * depth
+        self.count = 0
+
+    def submit(self, x, K_per_image):
+        """Enqueue one batch; returns its step index.  Asynchronous."""
+        i = self.count
+        s = i % self.depth
+        main = torch.cuda.current_stream(self.dev)
+        if i >= self.depth:
+            main.wait_event(self.ev_b[s])                 # slot s is free again
+        logits = self.model.forward_logits(x)
+        self.model.decode2d(logits, out=self.det[s])
+        self.ev_a[s].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_a[s])
+            decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
+            d = self.det[s]
+            rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk, self.boxes[s])
+            self.rec[s] = rdist.all_gather_records(rec) if self.gather else rec
+            self.ev_b[s].record(self.side)
+        self.count += 1
+        return i
+
+    def results(self, i):
+        """(world*B, topk, 32) records of step i (waits for it on the current stream)."""
+        s = i % self.depth
+        torch.cuda.current_stream(self.dev).wait_event(self.ev_b[s])
+        return self.rec[s]
+
+    def drain(self):
+        self.side.synchronize()
+        torch.cuda.current_stream(self.dev).synchronize()
