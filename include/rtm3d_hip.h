@@ -31,7 +31,7 @@ extern "C" {
 
 #define RTM3D_ABI_VERSION 1
 #define RTM3D_MAX_GROUPS 4
-#define RTM3D_MAX_TAPS 9
+#define RTM3D_MAX_TAPS 49
 
 typedef struct rtm3d_ctx rtm3d_ctx;
 
@@ -64,6 +64,10 @@ int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t bytes, int* id)
 int rtm3d_op_stem(rtm3d_ctx* ctx, int out_tensor, int ksize, int stride, int pad, int cout,
                   int w_blob, int bias_blob);
 
+/* Copy the caller's fp32 NCHW (B,3,H,W) image into a 4-channel padded NHWC fp16 tensor (4th channel
+ * zero, border >= 4): operand layout of the register-direct MFMA stem (kernel = 3 with cin = 4).      */
+int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor);
+
 /* Generic convolution descriptor (one launch; `groups` independent sub-problems on grid.z).
  * Covers conv KxK (any stride / dilation), 1x1 over channel slices of wider tensors (the DLA root
  * "concat" never materialises: producers write slices), grouped head convs, and the four
@@ -84,7 +88,8 @@ typedef struct rtm3d_conv_desc {
     int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
     int relu;
     int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
-    int kernel;                            /* 0 = MFMA implicit GEMM (cin % 64 == 0), 1 = direct dot2 (small cin) */
+    int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 1 = direct dot2 (small cin),
+                                              2 = MFMA 256x256 tile (cout % 256 == 0), 3 = register-direct MFMA (cin 4/16/32) */
     int bn_tile;                           /* MFMA: cout tile the weights were packed for (16/32/64/128) */
     int out_nchw_f32;                      /* 0, or 1..4 = index+1 into rtm3d_forward's out_logits[] */
     int out_H, out_W;                      /* only for out_nchw_f32 */

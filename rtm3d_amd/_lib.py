@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
 ABI_VERSION = 1
-MAX_GROUPS, MAX_TAPS = 4, 9
+MAX_GROUPS, MAX_TAPS = 4, 49
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
 c_double = ctypes.c_double
@@ -44,6 +44,7 @@ SIGNATURES = {
     'rtm3d_tensor_upload': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'rtm3d_blob_create': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int)]),
     'rtm3d_op_stem': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_op_input_nhwc4': (c_int, [c_void_p, c_int]),
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
     'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),

@@ -11,7 +11,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define RT_MAX_GROUPS 4
-#define RT_MAX_TAPS 9
+#define RT_MAX_TAPS 49
 
 // Geometry of one padded NHWC fp16 activation tensor as the kernels see it.
 struct TensorView {
@@ -70,12 +70,16 @@ struct SoftmaxKArgs {
     int zi_Hp, zi_Wp, zi_C, zi_P;  // z_in geometry
     int u_Hp[3], u_Wp[3], u_C[3], u_P[3];
     float* partial;                // [n_u][B][chunks][C][2] (max, sumexp)
+    float* stats;                  // [n_u][B][C][2] (max, 1/sum)
     int chunks, rows_per_chunk;
 };
 
 // kernel launchers (each returns hipGetLastError())
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, hipStream_t s);
+hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);
+bool conv_smallc_supported(int cin, int cout, int ntaps);
+hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s);
 hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStream_t s);
 bool conv_direct_supported(int cin, int cout, int ntaps);
 hipError_t launch_stem(const StemKArgs& a, int ksize, int cout, hipStream_t s);

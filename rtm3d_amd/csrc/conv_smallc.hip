@@ -1,0 +1,132 @@
+// Register-direct MFMA convolution for the few-channel, high-resolution layers
+// (DLA base_layer 3->16 7x7, level0 16->16, level1 16->32 s2, level2 entry 32->64; ResNet conv1 3->64).
+//
+// These layers are HBM-bound (72-124 FLOP/B): the goal is one coalesced pass over the input and the
+// output, with the arithmetic off the critical path.  With <= 32 input channels a 16x16x32 MFMA
+// K-step is "a few taps x all channels", and the 8 halves a lane feeds to the matrix core are 16
+// contiguous bytes of one (shifted) input pixel - so the pixel operand is loaded straight from global
+// memory into the MFMA operand registers (no LDS, no im2col), 16 consecutive pixels per instruction,
+// and the whole filter bank lives in registers (20-72 VGPRs) for the lifetime of the wave.
+//   CIN=16: K-step = taps (2s, 2s+1) x 16 ch      CIN=32: K-step = tap s x 32 ch
+//   CIN=4 : K-step = filter row ky: 4 lane groups x (2 adjacent pixels x 4 ch)   [stem, image stored
+//           as NHWC4 fp16 by nchw_to_nhwc4_kernel; the 4th channel and the 8th tap are zero-weighted]
+// Weights are the MFMA A operand (rows = output channels), pixels the B operand: each lane ends up with
+// 4 consecutive output channels of one pixel -> 8-byte NHWC stores, bias/ReLU fused.
+#include "common.h"
+
+struct __attribute__((aligned(8))) f16x8_a8 { f16 v[8]; };
+
+template <int CIN, int NCT, int S, int TPW>
+__global__ __launch_bounds__(256) void conv_smallc_kernel(const ConvKArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int frow = lane & 15, fk = lane >> 4;
+    const ConvGroupArgs& g = a.g[0];
+    const int ct0 = blockIdx.y * NCT;                       // first 16-channel tile of this block
+
+    // the filter bank: [cout tile][k-step][lane][8 halves]
+    f16x8 wf[NCT][S];
+    {
+        const f16* wp = a.wgt + g.w_off;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int s = 0; s < S; ++s) wf[c][s] = *(const f16x8*)(wp + ((size_t)((ct0 + c) * S + s) * 64 + lane) * 8);
+    }
+    // per-lane element offset of its 16-byte piece in every k-step
+    int koff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (CIN == 16) { int t = 2 * s + (fk >> 1); t = t < a.ntaps ? t : a.ntaps - 1; koff[s] = g.tap_off[t] + (fk & 1) * 8; }
+        else if (CIN == 32) koff[s] = g.tap_off[s] + fk * 8;
+        else { const int kx = 2 * fk < 6 ? 2 * fk : 6; koff[s] = g.tap_off[s * 7 + kx]; }
+    }
+    const int ntiles = (a.M + 15) / 16;
+#pragma unroll 1
+    for (int it = 0; it < TPW; ++it) {
+        const int tile = wave * TPW + it;
+        if (tile >= ntiles) break;
+        int m = tile * 16 + frow;
+        const bool valid = m < a.M;
+        m = valid ? m : a.M - 1;
+        const int n = m / a.HmWm, rem = m - n * a.HmWm;
+        const int y = rem / a.Wm, x = rem - y * a.Wm;
+        const f16* ip = a.in + ((size_t)(n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P) * a.in_C + g.in_coff;
+        f16x8 xf[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (CIN == 4) {
+                const f16x8_a8 t = *(const f16x8_a8*)(ip + koff[s]);
+                __builtin_memcpy(&xf[s], &t, 16);
+            } else {
+                xf[s] = *(const f16x8*)(ip + koff[s]);
+            }
+        }
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][s], xf[s], acc[c], 0, 0, 0);
+        if (valid) {
+            const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+            f16* op = (f16*)a.out + ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int c0 = (ct0 + c) * 16 + fk * 4;
+                const f32x4 b = *(const f32x4*)(a.bias + g.bias_off + c0);
+                f32x4 v = acc[c] + b;
+                if (a.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *(f16x4*)(op + c0) = h;
+            }
+        }
+    }
+}
+
+// fp32 NCHW (B,3,H,W) image -> padded NHWC4 fp16 (4th channel = 0): the stem's operand layout.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, f16* __restrict__ out, int B, int H, int W,
+                                                            int Hp, int Wp, int P) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H * W) return;
+    const int n = idx / (H * W), rem = idx - n * (H * W);
+    const int y = rem / W, x = rem - y * W;
+    const size_t plane = (size_t)H * W;
+    const float* p = in + (size_t)n * 3 * plane + (size_t)y * W + x;
+    f16x4 v = {(f16)p[0], (f16)p[plane], (f16)p[2 * plane], (f16)0.f};
+    *(f16x4*)(out + ((size_t)(n * Hp + y + P) * Wp + x + P) * 4) = v;
+}
+
+bool conv_smallc_supported(int cin, int cout, int ntaps) {
+    if (cin == 16 && ntaps == 9) return cout == 16 || cout == 32;
+    if (cin == 32 && (ntaps == 9 || ntaps == 1)) return cout == 64;
+    if (cin == 4 && ntaps == 49) return cout == 16 || cout == 64;
+    return false;
+}
+
+#define LAUNCH(CIN, NCT, S, TPW, GY)                                                                         \
+    do {                                                                                                     \
+        const int ntiles = (a.M + 15) / 16;                                                                  \
+        dim3 grid((ntiles + 4 * (TPW) - 1) / (4 * (TPW)), (GY), 1), block(256);                              \
+        hipLaunchKernelGGL((conv_smallc_kernel<CIN, NCT, S, TPW>), grid, block, 0, s, a);                    \
+    } while (0)
+
+hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s) {
+    if (a.cin == 16 && a.ntaps == 9 && a.cout == 16) LAUNCH(16, 1, 5, 8, 1);
+    else if (a.cin == 16 && a.ntaps == 9 && a.cout == 32) LAUNCH(16, 2, 5, 8, 1);
+    else if (a.cin == 32 && a.ntaps == 9 && a.cout == 64) LAUNCH(32, 2, 9, 8, 2);
+    else if (a.cin == 32 && a.ntaps == 1 && a.cout == 64) LAUNCH(32, 4, 1, 8, 1);
+    else if (a.cin == 4 && a.ntaps == 49 && a.cout == 16) LAUNCH(4, 1, 7, 8, 1);
+    else if (a.cin == 4 && a.ntaps == 49 && a.cout == 64) LAUNCH(4, 4, 7, 8, 1);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s) {
+    const int total = B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, out, B, H, W, Hp, Wp, P);
+    return hipGetLastError();
+}

@@ -73,25 +73,30 @@ __global__ __launch_bounds__(256) void softmax_reduce_kernel(const SoftmaxKArgs 
     out[0] = M; out[1] = S;
 }
 
-// pass 2: combine the partials and apply  z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i
+// pass 2: combine the per-chunk partials once per (u, image, channel): stats[u][b][c] = (max, 1/sum)
+__global__ __launch_bounds__(256) void softmax_combine_kernel(const SoftmaxKArgs a) {
+    const int n = blockIdx.x, ui = blockIdx.y, c = threadIdx.x;
+    const float* p = a.partial + (((size_t)ui * a.B + n) * a.chunks * a.C + c) * 2;
+    float mm = -INFINITY;
+    for (int k = 0; k < a.chunks; ++k) mm = fmaxf(mm, p[(size_t)k * a.C * 2]);
+    float ssum = 0.f;
+    for (int k = 0; k < a.chunks; ++k) {
+        const float mk = p[(size_t)k * a.C * 2];
+        if (mk != -INFINITY) ssum += p[(size_t)k * a.C * 2 + 1] * __expf(mk - mm);
+    }
+    float* o = a.stats + (((size_t)ui * a.B + n) * a.C + c) * 2;
+    o[0] = mm; o[1] = 1.f / ssum;
+}
+
+// pass 3: z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i
 __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a) {
     const int chunk = blockIdx.x, n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float M[3][4], invS[3][4];
     for (int ui = 0; ui < a.n_u; ++ui) {
+        const float* st = a.stats + (((size_t)ui * a.B + n) * a.C + lane * 4) * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = lane * 4 + e;
-            const float* p = a.partial + (((size_t)ui * a.B + n) * a.chunks * a.C + c) * 2;
-            float mm = -INFINITY;
-            for (int k = 0; k < a.chunks; ++k) mm = fmaxf(mm, p[(size_t)k * a.C * 2]);
-            float ssum = 0.f;
-            for (int k = 0; k < a.chunks; ++k) {
-                const float mk = p[(size_t)k * a.C * 2];
-                if (mk != -INFINITY) ssum += p[(size_t)k * a.C * 2 + 1] * __expf(mk - mm);
-            }
-            M[ui][e] = mm; invS[ui][e] = 1.f / ssum;
-        }
+        for (int e = 0; e < 4; ++e) { M[ui][e] = st[2 * e]; invS[ui][e] = st[2 * e + 1]; }
     }
     const int y0 = chunk * a.rows_per_chunk;
     const int y1 = min(y0 + a.rows_per_chunk, a.H);
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
 hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s) {
     if (a.C != 256 || a.n_u < 1 || a.n_u > 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(softmax_reduce_kernel, dim3(a.chunks, a.B, a.n_u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(softmax_combine_kernel, dim3(a.B, a.n_u, 1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(softmax_apply_kernel, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
     return hipGetLastError();
 }

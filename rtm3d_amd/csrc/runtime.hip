@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -78,7 +78,7 @@ static const size_t GUARD = 4096;   // halves of slack on both sides of every ac
 
 extern "C" int rtm3d_tensor_create(rtm3d_ctx* ctx, int B, int H, int W, int C, int pad, int* id) {
     if (!ctx || !id) RT_FAIL("tensor_create: null argument");
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || (C % 8) != 0) RT_FAIL("tensor_create: bad shape B=%d H=%d W=%d C=%d pad=%d (C must be a multiple of 8)", B, H, W, C, pad);
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || (C % 4) != 0) RT_FAIL("tensor_create: bad shape B=%d H=%d W=%d C=%d pad=%d (C must be a multiple of 4)", B, H, W, C, pad);
     Tensor t;
     t.B = B; t.H = H; t.W = W; t.C = C; t.P = pad; t.Hp = H + 2 * pad; t.Wp = W + 2 * pad;
     t.elems = (size_t)B * t.Hp * t.Wp * C;
@@ -248,6 +248,16 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = cout_pad * g; }
         op.kind = OP_CONV_MFMA; op.bn_tile = BN;
         op.name = d->ntaps == 1 ? "conv1x1_mfma" : (d->ntaps == 4 ? "deconv4x4_phase_mfma" : "conv3x3_mfma");
+    } else if (d->kernel == 3) {
+        if (d->groups != 1 || d->out_nchw_f32 || res) RT_FAIL("op_conv(smallc): groups/NCHW output/residual unsupported");
+        if (!conv_smallc_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(smallc): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
+        const int S = d->cin == 16 ? 5 : (d->cin == 32 ? d->ntaps : 7);
+        if (wbytes != (size_t)(d->cout / 16) * S * 64 * 8 * sizeof(f16)) RT_FAIL("op_conv(smallc): weight blob size mismatch");
+        if (bbytes != (size_t)d->cout * sizeof(float)) RT_FAIL("op_conv(smallc): bias blob size mismatch");
+        if (d->cin == 4 && in->P < 4) RT_FAIL("op_conv(smallc): the NHWC4 stem input needs a border of 4");
+        a.g[0].w_off = 0; a.g[0].bias_off = 0;
+        op.kind = OP_CONV_SMALLC;
+        op.name = d->cin == 4 ? "stem7x7_regmfma" : "conv_smallc_regmfma";
     } else {
         if (d->groups != 1 || d->out_nchw_f32) RT_FAIL("op_conv(direct): groups/NCHW output unsupported");
         if (!conv_direct_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(direct): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
@@ -257,6 +267,19 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         op.kind = OP_CONV_DIRECT;
         op.name = "conv_direct_dot2";
     }
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
+    Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    if (!o || o->C != 4) RT_FAIL("op_input_nhwc4: output tensor must have 4 channels");
+    Op op;
+    op.kind = OP_INPUT4; op.name = "nchw_f32_to_nhwc4_f16";
+    memset(&op.stem, 0, sizeof(op.stem));
+    op.stem.out = o->base; op.stem.B = o->B; op.stem.H = o->H; op.stem.W = o->W;
+    op.stem.out_Hp = o->Hp; op.stem.out_Wp = o->Wp; op.stem.out_P = o->P;
+    op.flops = 0; op.bytes = (double)o->B * o->H * o->W * (12.0 + 8.0);
     ctx->ops.push_back(op);
     return 0;
 }
@@ -306,6 +329,10 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
     RT_HIP(hipMalloc(&part, (size_t)n_u * a.B * a.chunks * a.C * 2 * sizeof(float)));
     ctx->extra.push_back(part);
     a.partial = (float*)part;
+    void* st = nullptr;
+    RT_HIP(hipMalloc(&st, (size_t)n_u * a.B * a.C * 2 * sizeof(float)));
+    ctx->extra.push_back(st);
+    a.stats = (float*)st;
     op.flops = 0;
     op.bytes = 2.0 * a.B * a.H * a.W * 256.0 * (2.0 * n_u + 2.0);
     ctx->ops.push_back(op);
@@ -327,6 +354,8 @@ static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_ou
             break;
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, s); break;
+        case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
+        case OP_INPUT4: e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
         case OP_CONV_DIRECT: e = launch_conv_direct(op.conv, 0, op.groups, s); break;
         case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
         case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;

@@ -121,6 +121,22 @@ class Plan(object):
                          'cout': cout, 'w': np.ascontiguousarray(w.transpose(2, 3, 1, 0)).astype(np.float32),
                          'bias': np.asarray(bias, np.float32)})
 
+    def input_nhwc4(self, out, name='input'):
+        """fp32 NCHW image -> 4-channel padded NHWC fp16 tensor (4th channel zero)."""
+        assert out.C == 4 and out.coff == 0 and self.tensors[out.tid]['pad'] >= 4
+        self.ops.append({'op': 'input4', 'name': name, 'out': out})
+
+    def stem_mfma(self, out, w, bias, stride, name=''):
+        """7x7 stem as a register-direct MFMA conv over the NHWC4 image (conv_smallc.hip)."""
+        cout, cin, k, _ = w.shape
+        assert cin == 3 and k == 7
+        Ho, Wo = self.dims(out)
+        x4 = self.tensor(Ho * stride, Wo * stride, 4, 4, name='input4')
+        self.input_nhwc4(x4)
+        w4 = np.zeros((cout, 4, k, k), np.float32)
+        w4[:, :3] = w
+        self.conv(x4, out, w4, bias, stride=stride, relu=True, name=name)
+
     def softmax_fuse(self, z_in, z_out, us, name=''):
         self.ops.append({'op': 'softmax', 'name': name, 'z_in': z_in, 'z_out': z_out, 'us': list(us)})
 
@@ -128,7 +144,8 @@ class Plan(object):
         f = 0.0
         for op in self.ops:
             if op['op'] == 'conv':
-                f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['groups'] * op['cin'] * len(op['taps'][0]) * op['cout']
+                cin = 3 if op['cin'] == 4 else op['cin']          # NHWC4 stem: the 4th channel is zero padding
+                f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['groups'] * cin * len(op['taps'][0]) * op['cout']
             elif op['op'] == 'stem':
                 H, W = self.dims(op['out'])
                 f += 2.0 * self.B * H * W * op['k'] * op['k'] * 3 * op['cout']
@@ -183,7 +200,7 @@ def _build_dla(P, sd, H, W, feat_out):
     ch = DLA34_CHANNELS
     t_base = P.tensor(H, W, ch[0], 1, name='base')
     w, b = fold_bn(sd, 'backbone.base_layer.0', 'backbone.base_layer.1')
-    P.stem(t_base, w, b, 1, name='backbone.base_layer')
+    P.stem_mfma(t_base, w, b, 1, name='backbone.base_layer')
     t_l0 = P.tensor(H, W, ch[0], 1, name='level0')
     w, b = fold_bn(sd, 'backbone.level0.0', 'backbone.level0.1')
     P.conv(t_base, t_l0, w, b, relu=True, name='backbone.level0')
@@ -222,7 +239,7 @@ def _build_dla(P, sd, H, W, feat_out):
 def _build_resnet(P, sd, H, W, depth, feat_out):
     t_c1 = P.tensor(H // 2, W // 2, 64, 1, name='conv1')
     w, b = fold_bn(sd, 'backbone.conv1', 'backbone.bn1')
-    P.stem(t_c1, w, b, 2, name='backbone.conv1')
+    P.stem_mfma(t_c1, w, b, 2, name='backbone.conv1')
     x = P.tensor(H // 4, W // 4, 64, 1, name='pool')
     P.maxpool(t_c1, x, 3, 2, 1, name='backbone.maxpool')
     inpl = 64
@@ -330,7 +347,7 @@ def choose_variant(cin, cout, M, groups, out_nchw):
     """2 = 256x256-tile 8-wave kernel (conv_mfma256.hip) when the layer has enough tiles to fill the
     chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 1 = direct (small cin)."""
     if cin % 64:
-        return 1
+        return 3 if cin in (4, 16, 32) else 1
     if not out_nchw and cout % 256 == 0 and ((M + 255) // 256) * (cout // 256) * groups >= 512:
         return 2
     return 0
@@ -351,6 +368,30 @@ def pack_mfma_weights(wt, bn):
     src = cs ^ (r & 7)                                              # chunk stored at position cs of row r
     w = w[:, :, :, r, src, :]
     return np.ascontiguousarray(w).astype(np.float16).reshape(-1), cout_pad
+
+
+def pack_smallc_weights(wt):
+    """wt: (taps, cout, cin) fp32 -> fp16 [cout/16][k-step][lane = fk*16 + row][8] for conv_smallc.hip.
+    cin=16: k-step s = taps (2s, 2s+1); cin=32: k-step = tap; cin=4: k-step = filter row of 7 taps
+    (+1 zero tap), lane group fk = taps (2fk, 2fk+1), 4 channels each."""
+    taps, cout, cin = wt.shape
+    S = 5 if cin == 16 else (taps if cin == 32 else 7)
+    out = np.zeros((cout // 16, S, 4, 16, 8), np.float32)              # ct, s, fk, row, j
+    w = wt.reshape(taps, cout // 16, 16, cin)
+    for s in range(S):
+        for fk in range(4):
+            if cin == 16:
+                t = 2 * s + (fk >> 1)
+                if t < taps:
+                    out[:, s, fk] = w[t][:, :, (fk & 1) * 8:(fk & 1) * 8 + 8]
+            elif cin == 32:
+                out[:, s, fk] = w[s][:, :, fk * 8:fk * 8 + 8]
+            else:
+                for half in range(2):
+                    kx = 2 * fk + half
+                    if kx < 7:
+                        out[:, s, fk, :, half * 4:half * 4 + 4] = w[s * 7 + kx]
+    return np.ascontiguousarray(out).astype(np.float16).reshape(-1)
 
 
 def pack_direct_weights(wt):
@@ -414,6 +455,10 @@ class RealizedPlan(object):
             packed = [pack_mfma_weights(op['w'][g], 256)[0] for g in range(G)]
             d.kernel, d.bn_tile = 2, 256
             d.w_blob, d.bias_blob = self._blob(np.concatenate(packed)), self._blob(np.ascontiguousarray(op['bias'], np.float32).reshape(-1))
+        elif variant == 3:
+            assert G == 1
+            d.kernel, d.bn_tile = 3, 0
+            d.w_blob, d.bias_blob = self._blob(pack_smallc_weights(op['w'][0])), self._blob(op['bias'][0])
         elif op['cin'] % 64 == 0:
             bn = op.get('bn_tile') or choose_bn_tile(op['cout'], M)
             packed, biases = [], []
@@ -430,6 +475,9 @@ class RealizedPlan(object):
             d.kernel, d.bn_tile = 1, 0
             d.w_blob, d.bias_blob = self._blob(pack_direct_weights(op['w'][0])), self._blob(op['bias'][0])
         _lib.check(self.lib.rtm3d_op_conv(self.ctx, ctypes.byref(d)), 'op_conv ' + op['name'])
+
+    def _op_input4(self, op):
+        _lib.check(self.lib.rtm3d_op_input_nhwc4(self.ctx, self.tids[op['out'].tid]), 'op_input_nhwc4')
 
     def _op_maxpool(self, op):
         _lib.check(self.lib.rtm3d_op_maxpool(self.ctx, self.tids[op['inp'].tid], op['inp'].coff, self.tids[op['out'].tid],

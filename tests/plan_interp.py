@@ -29,6 +29,10 @@ def run_plan(plan, x_nchw, half=False):
             y = torch.nn.functional.conv2d(x_nchw, w, torch.from_numpy(op['bias']), op['stride'], op['pad']).relu()
             buf, P, H, W = view(o)
             buf[:, P:P + H, P:P + W, o.coff:o.coff + o.C] = rnd(y.permute(0, 2, 3, 1))
+        elif op['op'] == 'input4':
+            o = op['out']
+            buf, P, H, W = view(o)
+            buf[:, P:P + H, P:P + W, 0:3] = rnd(x_nchw.permute(0, 2, 3, 1))
         elif op['op'] == 'conv':
             Hm, Wm, s, sc = op['Hm'], op['Wm'], op['in_stride'], op['out_scale']
             for g in range(op['groups']):
