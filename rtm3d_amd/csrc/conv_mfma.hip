@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     // XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD -> give them the same pixel tile.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
+    const int chunk = (a.MT + 7) >> 3;           // each XCD walks a contiguous run of pixel tiles (shared halo rows)
     const int ntile = j % a.NT;
-    const int mtile = (j / a.NT) * 8 + xcd;
+    const int mtile = xcd * chunk + j / a.NT;
     if (mtile >= a.MT) return;
     const ConvGroupArgs& g = a.g[blockIdx.y];
 

@@ -37,9 +37,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     const int wp = wave & 1, wc = wave >> 1;         // 2 pixel groups x 4 channel groups
 
     const int bid = blockIdx.x;
+    // XCD-aware order: workgroups b, b+8, b+16.. share an XCD (L2).  Each XCD walks a CONTIGUOUS run of
+    // pixel tiles (neighbouring tiles share halo rows) and, per pixel tile, all NT channel tiles.
     const int xcd = bid & 7, jb = bid >> 3;
+    const int chunk = (a.MT + 7) >> 3;
     const int ntile = jb % a.NT;
-    const int mtile = (jb / a.NT) * 8 + xcd;
+    const int mtile = xcd * chunk + jb / a.NT;
     if (mtile >= a.MT) return;
     const ConvGroupArgs& g = a.g[blockIdx.y];
     const int T = a.ksteps;
