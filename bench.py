@@ -156,11 +156,22 @@ def main():
         total_images = B * world * args.steps
         flops_fwd = plan.plan.total_flops()
         d = info[dom]
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be collected live inside a timed
+        # run, so the per-launch figure comes from the committed rocprofv3 --pmc profile of this workload
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_heads.json')) as f:
+                pmc = json.load(f)
+            if B == 32 and (H, W) == (384, 1280) and d['name'] in pmc['kernels']:
+                traffic = pmc['kernels'][d['name']]['hbm_bytes_corrected'] / 1e9
+                traffic_src = 'profiles/r01_pmc_heads.json (GB per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024)'
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (d['kernel'], d['name']),
                 'achieved': d['flops'] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
                 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': (d['flops'] / (dom_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS) if dom_ms > 0 else None,
-                'traffic': None, 'launch_ms': dom_ms, 'launches_timed': dom_n,
+                'traffic': traffic, 'traffic_source': traffic_src, 'launch_ms': dom_ms, 'launches_timed': dom_n,
                 'flops_per_launch': d['flops'],
                 'whole_forward_frac': flops_fwd / (sum(i['ms'] for i in info) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
         out = {'metric': 'images_per_sec', 'value': total_images / dt, 'unit': 'images/s', 'n_gpus': world,

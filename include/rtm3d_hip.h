@@ -96,6 +96,12 @@ typedef struct rtm3d_conv_desc {
 } rtm3d_conv_desc;
 int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
 
+/* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
+ * input = the 4 x 256-channel tensor written by the grouped head conv, outputs = rtm3d_forward's four
+ * fp32 NCHW logit buffers with cout4[i] channels.  Weights: fp16 [head][tap][8 k-blocks][64 lanes][8]
+ * (MFMA fragment order, 16 zero-padded rows per head), bias fp32 [head][16].                          */
+int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, const int* cout4);
+
 /* Max pooling k x k / stride / pad over channel slice, NHWC fp16 (models/nets/dla.py:170-172,
  * models/nets/resnet.py:128).  Inputs are post-ReLU (>= 0) so the zero border equals -inf padding. */
 int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff,

@@ -74,7 +74,19 @@ struct SoftmaxKArgs {
     int chunks, rows_per_chunk;
 };
 
+struct HeadOutArgs {
+    const f16* in;          // h2: padded NHWC, 4 x 256 channels
+    const f16* wgt;         // [head][tap][chunk*2+kk][lane][8]  (16 output rows, zero padded)
+    const float* bias;      // [head][16]
+    float* out[4];          // fp32 NCHW logits per head
+    int cout[4];
+    int B, H, W;
+    int in_Hp, in_Wp, in_C, in_P;
+    int tiles_x, tiles_y;
+};
+
 // kernel launchers (each returns hipGetLastError())
+hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, hipStream_t s);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -37,6 +37,7 @@ struct Op {
     StemKArgs stem; int stem_cout;
     PoolKArgs pool;
     SoftmaxKArgs sm;
+    HeadOutArgs ho;
 };
 
 struct rtm3d_ctx {
@@ -284,6 +285,30 @@ extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
     return 0;
 }
 
+extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, const int* cout4) {
+    Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
+    if (!in || !cout4) RT_FAIL("op_headout: bad arguments");
+    if (in->C != 1024 || in->P < 1) RT_FAIL("op_headout: input must be the 4 x 256 channel head tensor with a border >= 1");
+    size_t wb = 0, bb = 0;
+    const f16* w = (const f16*)get_blob(ctx, w_blob, &wb);
+    const float* b = (const float*)get_blob(ctx, bias_blob, &bb);
+    if (!w || !b || wb != (size_t)4 * 9 * 8 * 64 * 8 * sizeof(f16) || bb != 64 * sizeof(float)) RT_FAIL("op_headout: weight/bias blob size mismatch");
+    Op op;
+    op.kind = OP_HEADOUT; op.name = "conv3x3_headout_halo";
+    HeadOutArgs& a = op.ho;
+    memset(&a, 0, sizeof(a));
+    a.in = in->base; a.wgt = w; a.bias = b;
+    int csum = 0;
+    for (int i = 0; i < 4; ++i) { if (cout4[i] < 1 || cout4[i] > 16) RT_FAIL("op_headout: cout must be in [1,16]"); a.cout[i] = cout4[i]; csum += cout4[i]; }
+    a.B = in->B; a.H = in->H; a.W = in->W;
+    a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_P = in->P;
+    a.tiles_x = (in->W + 31) / 32; a.tiles_y = (in->H + 7) / 8;
+    op.flops = 2.0 * in->B * in->H * in->W * 9.0 * 256.0 * csum;
+    op.bytes = (double)in->B * in->H * in->W * (1024.0 * 2 + csum * 4.0);
+    ctx->ops.push_back(op);
+    return 0;
+}
+
 extern "C" int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff,
                                 int channels, int ksize, int stride, int pad) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
@@ -356,6 +381,12 @@ static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_ou
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
+        case OP_HEADOUT: {
+            HeadOutArgs a = op.ho;
+            for (int i = 0; i < 4; ++i) a.out[i] = d_out[i];
+            e = launch_conv_headout(a, s);
+            break;
+        }
         case OP_CONV_DIRECT: e = launch_conv_direct(op.conv, 0, op.groups, s); break;
         case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
         case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;

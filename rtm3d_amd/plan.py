@@ -137,6 +137,12 @@ class Plan(object):
         w4[:, :3] = w
         self.conv(x4, out, w4, bias, stride=stride, relu=True, name=name)
 
+    def headout(self, inp, ws, biases, name='heads.out'):
+        """The four final 3x3 convs (cout <= 16 each) in one halo-tile launch -> fp32 NCHW logits."""
+        assert inp.C == 1024 and inp.coff == 0 and len(ws) == 4
+        self.ops.append({'op': 'headout', 'name': name, 'inp': inp, 'w': [np.asarray(w, np.float32) for w in ws],
+                         'bias': [np.asarray(b, np.float32) for b in biases]})
+
     def softmax_fuse(self, z_in, z_out, us, name=''):
         self.ops.append({'op': 'softmax', 'name': name, 'z_in': z_in, 'z_out': z_out, 'us': list(us)})
 
@@ -146,6 +152,9 @@ class Plan(object):
             if op['op'] == 'conv':
                 cin = 3 if op['cin'] == 4 else op['cin']          # NHWC4 stem: the 4th channel is zero padding
                 f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['groups'] * cin * len(op['taps'][0]) * op['cout']
+            elif op['op'] == 'headout':
+                H, W = self.dims(op['inp'])
+                f += 2.0 * self.B * H * W * 9 * 256 * sum(w.shape[0] for w in op['w'])
             elif op['op'] == 'stem':
                 H, W = self.dims(op['out'])
                 f += 2.0 * self.B * H * W * op['k'] * op['k'] * 3 * op['cout']
@@ -324,9 +333,8 @@ def build_plan(state_dict, backbone, B, H, W):
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in HEADS])
     P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(4)], [P.sub(h2, g * oc, oc) for g in range(4)], ws, bs,
                    relu=True, name='heads.conv_d1')
-    for g, (seq, last, cout) in enumerate(HEADS):
-        w, b = fold_bn(sd, 'detect_header.%s.%s' % (seq, last))
-        P.conv(P.sub(h2, g * oc, oc), None, w, b, name='heads.%s' % last, out_nchw=g + 1, out_hw=fh[0])
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%s' % (seq, last)) for seq, last, _ in HEADS])
+    P.headout(h2, ws, bs, name='heads.out_convs')
     return P
 
 
@@ -392,6 +400,18 @@ def pack_smallc_weights(wt):
                     if kx < 7:
                         out[:, s, fk, :, half * 4:half * 4 + 4] = w[s * 7 + kx]
     return np.ascontiguousarray(out).astype(np.float16).reshape(-1)
+
+
+def pack_headout_weights(ws, biases):
+    """4 x (cout<=16, 256, 3, 3) -> fp16 [head][tap][chunk*2+kk][lane=fk*16+row][8], fp32 bias [head][16]."""
+    out = np.zeros((4, 9, 8, 4, 16, 8), np.float32)                    # head, tap, kblk, fk, row, j
+    bias = np.zeros((4, 16), np.float32)
+    for h, (w, b) in enumerate(zip(ws, biases)):
+        co = w.shape[0]
+        wt = w.reshape(co, 8, 4, 8, 9)                                  # cout, kblk(=cin/32), fk, j, tap
+        out[h, :, :, :, :co, :] = wt.transpose(4, 1, 2, 0, 3)
+        bias[h, :co] = b
+    return np.ascontiguousarray(out).astype(np.float16).reshape(-1), bias.reshape(-1)
 
 
 def pack_direct_weights(wt):
@@ -475,6 +495,11 @@ class RealizedPlan(object):
             d.kernel, d.bn_tile = 1, 0
             d.w_blob, d.bias_blob = self._blob(pack_direct_weights(op['w'][0])), self._blob(op['bias'][0])
         _lib.check(self.lib.rtm3d_op_conv(self.ctx, ctypes.byref(d)), 'op_conv ' + op['name'])
+
+    def _op_headout(self, op):
+        w, b = pack_headout_weights(op['w'], op['bias'])
+        co = (ctypes.c_int * 4)(*[x.shape[0] for x in op['w']])
+        _lib.check(self.lib.rtm3d_op_headout(self.ctx, self.tids[op['inp'].tid], self._blob(w), self._blob(b), co), 'op_headout')
 
     def _op_input4(self, op):
         _lib.check(self.lib.rtm3d_op_input_nhwc4(self.ctx, self.tids[op['out'].tid]), 'op_input_nhwc4')

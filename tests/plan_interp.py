@@ -59,6 +59,12 @@ def run_plan(plan, x_nchw, half=False):
                     o = op['out'][g]
                     obuf, Po, Ho, Wo = view(o)
                     obuf[:, Po + oy: Po + oy + (Hm - 1) * sc + 1: sc, Po + ox: Po + ox + (Wm - 1) * sc + 1: sc, o.coff:o.coff + o.C] = rnd(acc)
+        elif op['op'] == 'headout':
+            i = op['inp']
+            ibuf, Pi, Hi, Wi = view(i)
+            for h in range(4):
+                xin = ibuf[:, Pi - 1:Pi + Hi + 1, Pi - 1:Pi + Wi + 1, h * 256:(h + 1) * 256].permute(0, 3, 1, 2)
+                outs[h] = torch.nn.functional.conv2d(xin, rnd(torch.from_numpy(op['w'][h])), torch.from_numpy(op['bias'][h]))
         elif op['op'] == 'maxpool':
             i, o = op['inp'], op['out']
             ibuf, Pi, Hi, Wi = view(i)
