@@ -48,7 +48,9 @@ def parse_args():
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
+    ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
 
@@ -104,7 +106,7 @@ def main():
     topk = int(cfg.DETECTOR.TOPK_CANDIDATES)
 
     from rtm3d_amd.pipeline import Detect3DPipeline
-    pipe = Detect3DPipeline(model, B, dev, gather=True) if not args.serial else None
+    pipe = Detect3DPipeline(model, B, dev, gather=True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus) if not args.serial else None
 
     def step():
         if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
@@ -182,6 +184,8 @@ def main():
                           'global_batch': B * world, 'parallelism': 'dp%d' % world,
                           'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9},
                'roofline': roof}
+        if args.diag_no_decode3d:
+            out['INVALID'] = 'diagnostic run without the 3D decode'
         if args.per_op:
             tot = sum(i['ms'] for i in info)
             print('%-28s %-22s %9s %9s %8s' % ('op', 'kernel', 'ms', 'TFLOP/s', 'GB/s'), file=sys.stderr)

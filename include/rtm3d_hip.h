@@ -162,6 +162,11 @@ int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, cons
                          const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
                          const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
 
+/* Stream restricted to `n_cus` compute units (hipExtStreamCreateWithCUMask) for the latency-bound
+ * 3D decode of the two-stream pipeline; destroy with rtm3d_stream_destroy.                          */
+int rtm3d_stream_create_cumask(int device, int n_cus, void** stream);
+int rtm3d_stream_destroy(void* stream);
+
 /* Cross-check entry: identical arguments and results to rtm3d_decode3d, computed by the
  * one-lane-per-object form of the solver (slow; used by the parity tests only).                     */
 int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,

@@ -59,6 +59,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_decode3d': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
+    'rtm3d_stream_create_cumask': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'rtm3d_stream_destroy': (c_int, [c_void_p]),
     'rtm3d_decode3d_scalar': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     'rtm3d_decode3d_slots': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

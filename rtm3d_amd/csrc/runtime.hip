@@ -464,3 +464,27 @@ extern "C" int rtm3d_op_info(rtm3d_ctx* ctx, int i, double* flops, double* bytes
     if (name) *name = ctx->ops[i].name.c_str();
     return 0;
 }
+
+// A HIP stream whose kernels may only run on the first `n_cus` compute units (hipExtStreamCreateWithCUMask).
+// Used for the latency-bound 3D decode: its few long-lived wavefronts then never sit on the CUs the
+// MFMA convolutions of the next batch need whole (LDS/VGPR co-residency), see rtm3d_amd/pipeline.py.
+extern "C" int rtm3d_stream_create_cumask(int device, int n_cus, void** stream) {
+    if (!stream || n_cus < 1) RT_FAIL("stream_create_cumask: bad arguments");
+    RT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device));
+    const int total = prop.multiProcessorCount;
+    if (n_cus > total) n_cus = total;
+    const int words = (total + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    RT_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()));
+    *stream = (void*)s;
+    return 0;
+}
+
+extern "C" int rtm3d_stream_destroy(void* stream) {
+    if (stream) RT_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}

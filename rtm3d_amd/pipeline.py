@@ -11,6 +11,8 @@ Outputs are double-buffered (slot i % 2); the main stream waits for B_{i-2} befo
 overwrites slot i % 2.  No host synchronisation inside; `results(i)` hands out the records of a
 finished step after waiting on B_i.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,7 +22,8 @@ from . import distributed as rdist
 
 
 class Detect3DPipeline(object):
-    def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=2):
+    def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=2, decode3d=True,
+                 side_cus=0):
         self.model, self.B, self.dev = model, batch, torch.device(device)
         self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
         dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
@@ -28,15 +31,29 @@ class Detect3DPipeline(object):
         self.dim_ref = torch.as_tensor(np.asarray(dim_ref, np.float64), device=self.dev)
         self.ref_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=self.dev)
         self.gather = gather
+        self.decode3d = decode3d          # False: diagnostic only (measures what the 3D decode costs the pipeline)
         self.depth = depth
         with torch.cuda.device(self.dev):
-            self.side = torch.cuda.Stream(device=self.dev, priority=-1)   # high priority: few, long, latency-bound waves
+            self.side = self._make_side_stream(side_cus)
             self.det = [Detections(batch, self.topk, self.dev) for _ in range(depth)]
             self.boxes = [Boxes3D(batch * self.topk, self.dev) for _ in range(depth)]
             self.ev_a = [torch.cuda.Event() for _ in range(depth)]
             self.ev_b = [torch.cuda.Event() for _ in range(depth)]
         self.rec = [None] * depth
         self.count = 0
+
+    def _make_side_stream(self, side_cus):
+        """Side stream confined to `side_cus` CUs: the decode's long-lived waves stay off the CUs that the
+        256x256-tile convolutions of the next batch need whole (they cannot co-reside: VGPR/LDS)."""
+        if side_cus and side_cus > 0:
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            _lib.check(lib.rtm3d_stream_create_cumask(self.dev.index, int(side_cus), ctypes.byref(h)), 'stream_create_cumask')
+            self._side_handle = h
+            return torch.cuda.ExternalStream(h.value, device=self.dev)
+        return torch.cuda.Stream(device=self.dev, priority=int(os.environ.get('RTM3D_SIDE_PRIO', '-1')))
 
     def submit(self, x, K_per_image):
         """Enqueue one batch; returns its step index.  Asynchronous."""
@@ -50,7 +67,8 @@ class Detect3DPipeline(object):
         self.ev_a[s].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_a[s])
-            decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
+            if self.decode3d:
+                decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
             d = self.det[s]
             rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk, self.boxes[s])
             self.rec[s] = rdist.all_gather_records(rec) if self.gather else rec
