@@ -88,27 +88,37 @@ __device__ static inline double lbw_dot8(const double* a, const double* b) {
     return s;
 }
 
-// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block, in place.
+// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block (n <= LB_M), in place.
+// One template instance per pivot: the inner trip counts are compile-time constants, so all LDS
+// operands of a step are issued together (a rolled loop pays one LDS round trip per term).
+// Every sum still runs in index order.
+template <int J>
+__device__ static inline int lbw_potrf_step(double* a, int lda, int n, int lane) {
+    const int i = J + 1 + lane;
+    const bool act = i < n;
+    const int ic = act ? i : J;
+    double cj[J > 0 ? J : 1], ci[J > 0 ? J : 1];
+#pragma unroll
+    for (int k = 0; k < J; ++k) { cj[k] = a[J * lda + k]; ci[k] = a[ic * lda + k]; }
+    const double ajj0 = a[J * lda + J], aij = a[ic * lda + J];
+    double s = 0.0, dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) { s += cj[k] * cj[k]; dot += cj[k] * ci[k]; }
+    double ajj = ajj0 - s;
+    if (!(ajj > 0.0)) return J + 1;                     // uniform
+    ajj = sqrt(ajj);
+    const double rinv = 1.0 / ajj;
+    const double v = (aij - dot) * rinv;
+    WSYNC();                                            // everyone has read column J / a(J,J)
+    if (act) a[i * lda + J] = v;
+    if (lane == 0) a[J * lda + J] = ajj;
+    WSYNC();
+    return 0;
+}
+#define LBW_PSTEP(J) if (n <= J) return 0; { const int r_ = lbw_potrf_step<J>(a, lda, n, lane); if (r_) return r_; }
 __device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
-    for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-        for (int k = 0; k < j; ++k) s += a[j * lda + k] * a[j * lda + k];
-        double ajj = a[j * lda + j] - s;
-        if (!(ajj > 0.0)) return j + 1;                 // uniform
-        ajj = sqrt(ajj);
-        const double rinv = 1.0 / ajj;
-        const int i = j + 1 + lane;
-        double v = 0.0;
-        if (i < n) {
-            double dot = 0.0;
-            for (int k = 0; k < j; ++k) dot += a[j * lda + k] * a[i * lda + k];
-            v = (a[i * lda + j] - dot) * rinv;
-        }
-        WSYNC();                                        // everyone has read column j / a(j,j)
-        if (i < n) a[i * lda + j] = v;
-        if (lane == 0) a[j * lda + j] = ajj;
-        WSYNC();
-    }
+    LBW_PSTEP(0) LBW_PSTEP(1) LBW_PSTEP(2) LBW_PSTEP(3) LBW_PSTEP(4)
+    LBW_PSTEP(5) LBW_PSTEP(6) LBW_PSTEP(7) LBW_PSTEP(8) LBW_PSTEP(9)
     return 0;
 }
 
@@ -146,23 +156,50 @@ __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double
     return 0;
 }
 
+// forward substitution U' x = b for ONE right-hand side owned by this lane (n <= LB_M), unrolled
+template <int J>
+__device__ static inline void lbw_rhs_step(const double* u, double* bv, int* bad) {
+    const double ajj = u[J * LB_M2 + J];
+    if (ajj == 0.0) { *bad = 1; return; }
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) dot += u[J * LB_M2 + k] * bv[k];
+    bv[J] = (bv[J] - dot) / ajj;
+}
+#define LBW_RSTEP(J) if (n > J && !bad) lbw_rhs_step<J>(u, bv, &bad);
+__device__ static inline int lbw_rhs_solve(const double* u, double* b, int n) {
+    double bv[LB_M];
+#pragma unroll
+    for (int j = 0; j < LB_M; ++j) bv[j] = b[j < n ? j : 0];
+    int bad = 0;
+    LBW_RSTEP(0) LBW_RSTEP(1) LBW_RSTEP(2) LBW_RSTEP(3) LBW_RSTEP(4)
+    LBW_RSTEP(5) LBW_RSTEP(6) LBW_RSTEP(7) LBW_RSTEP(8) LBW_RSTEP(9)
+#pragma unroll
+    for (int j = 0; j < LB_M; ++j) if (j < n) b[j] = bv[j];
+    return bad;
+}
+
 __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, int col, int head, int lane) {
     const int m = LB_M, n = LB_N;
     if (iupdat > m) {
-        // shift the old part of WN1 one step up-left; two-phase (read all, then write all)
-        double v[3]; int dst[3]; int cnt = 0;
-        int e = 0;
-        for (int jy = 1; jy <= m - 1; ++jy) {
-            const int js = m + jy;
-            for (int k = 0; k < m - jy; ++k, ++e)
-                if ((e & 63) == lane) { v[cnt] = VWN1_(jy + 1 + k, jy + 1); dst[cnt++] = (jy - 1) * LB_M2 + (jy + k - 1); }
-            for (int k = 0; k < m - jy; ++k, ++e)
-                if ((e & 63) == lane) { v[cnt] = VWN1_(js + 1 + k, js + 1); dst[cnt++] = (js - 1) * LB_M2 + (js + k - 1); }
-            for (int k = 0; k < m - 1; ++k, ++e)
-                if ((e & 63) == lane) { v[cnt] = VWN1_(m + 2 + k, jy + 1); dst[cnt++] = (jy - 1) * LB_M2 + (m + 1 + k - 1); }
+        // shift the old part of WN1 one step up-left: three 9x9 index grids (lower triangles of the (1,1)
+        // and (2,2) blocks, the full (2,1) block); two-phase (read all, then write all); slots are
+        // statically indexed so they stay in registers (a scan with a running slot counter went to scratch
+        // and cost 14k cycles per iteration)
+        double v[6]; int dst[6]; bool ok[6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = lane + 64 * r;
+            const bool in = e < (m - 1) * (m - 1);
+            const int ee = in ? e : 0;
+            const int c = ee / (m - 1) + 1, q = ee % (m - 1) + 1;     // column 1..m-1, row index 1..m-1
+            ok[3 * r + 0] = in && q >= c; v[3 * r + 0] = VWN1_(q + 1, c + 1);         dst[3 * r + 0] = (c - 1) * LB_M2 + (q - 1);
+            ok[3 * r + 1] = in && q >= c; v[3 * r + 1] = VWN1_(m + q + 1, m + c + 1); dst[3 * r + 1] = (m + c - 1) * LB_M2 + (m + q - 1);
+            ok[3 * r + 2] = in;           v[3 * r + 2] = VWN1_(m + q + 1, c + 1);     dst[3 * r + 2] = (c - 1) * LB_M2 + (m + q - 1);
         }
         WSYNC();
-        for (int q = 0; q < cnt; ++q) w->wn1[dst[q]] = v[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) if (ok[q]) w->wn1[dst[q]] = v[q];
         WSYNC();
     }
     {
@@ -203,15 +240,7 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
     const int col2 = 2 * col;
     {   // L^-1 (-L_a' + R_z'): one right-hand side (column) per lane
         int bad = 0;
-        if (lane < col) {
-            double* b = &VWN_(1, col + 1 + lane);
-            for (int j = 0; j < col; ++j) {
-                if (w->wn[j * LB_M2 + j] == 0.0) { bad = 1; break; }
-                double dot = 0.0;
-                for (int k = 0; k < j; ++k) dot += w->wn[j * LB_M2 + k] * b[k];
-                b[j] = (b[j] - dot) / w->wn[j * LB_M2 + j];
-            }
-        }
+        if (lane < col) bad = lbw_rhs_solve(w->wn, &VWN_(1, col + 1 + lane), col);
         if (__any(bad)) return -1;
         WSYNC();
     }
@@ -275,15 +304,23 @@ __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, i
     if (lane < n) { VWS_(lane + 1, *itail) = w->d[lane]; VWY_(lane + 1, *itail) = w->r[lane]; }
     *theta = rr / dr;
     if (iupdat > m) {
-        double v[2]; int dst[2], which[2]; int cnt = 0, e = 0;
-        for (int j = 1; j <= *col - 1; ++j) {
-            for (int k = 0; k < j; ++k, ++e)
-                if ((e & 63) == lane) { v[cnt] = VSS_(2 + k, j + 1); dst[cnt] = (j - 1) * LB_M + k; which[cnt++] = 0; }
-            for (int k = 0; k < *col - j; ++k, ++e)
-                if ((e & 63) == lane) { v[cnt] = VSY_(j + 1 + k, j + 1); dst[cnt] = (j - 1) * LB_M + (j + k - 1); which[cnt++] = 1; }
+        // move the old information: SS upper triangle and SY lower triangle one step up-left (9x9 grids)
+        double vs[2], vy[2]; int dst[2]; bool oks[2], oky[2];
+        const int cm = *col - 1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = lane + 64 * r;
+            const bool in0 = e < (m - 1) * (m - 1);
+            const int ee = in0 ? e : 0;
+            const int j = ee / (m - 1) + 1, q = ee % (m - 1) + 1;     // column j, row q in 1..m-1
+            const bool in = in0 && j <= cm && q <= cm;
+            oks[r] = in && q <= j; oky[r] = in && q >= j;
+            vs[r] = VSS_(q + 1, j + 1); vy[r] = VSY_(q + 1, j + 1);
+            dst[r] = (j - 1) * LB_M + (q - 1);
         }
         WSYNC();
-        for (int q = 0; q < cnt; ++q) { if (which[q]) w->sy[dst[q]] = v[q]; else w->ss[dst[q]] = v[q]; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { if (oks[r]) w->ss[dst[r]] = vs[r]; if (oky[r]) w->sy[dst[r]] = vy[r]; }
     }
     WSYNC();
     const int j = lane + 1;

@@ -1,0 +1,179 @@
+"""GPU (-m gpu): every HIP kernel variant on its own, through the C ABI, against a plain PyTorch fp32
+reference of the same op (fp16-rounded operands, fp32 math), including ragged shapes: pixel counts
+that are not multiples of the 128/256-pixel tiles, channel slices of wider tensors, strides, dilation,
+the four transposed-convolution phases, residual + ReLU epilogues."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from rtm3d_amd import plan as plan_mod, _lib     # noqa: E402
+
+
+def _run(P, feeds, fetch, x_img=None):
+    R = plan_mod.RealizedPlan(P, 0)
+    for s, arr in feeds:
+        arr = np.ascontiguousarray(arr, np.float32)
+        _lib.check(R.lib.rtm3d_tensor_upload(R.ctx, R.tids[s.tid], s.coff, s.C, arr.ctypes.data_as(ctypes.c_void_p)))
+    B = P.B
+    xin = torch.zeros(16, device='cuda') if x_img is None else x_img.cuda().contiguous()
+    outs = [torch.zeros(B * 16 * 64 * 64, device='cuda') for _ in range(4)]
+    R.forward(torch.cuda.current_stream().cuda_stream, xin.data_ptr(), [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    res = [R.download(s) for s in fetch]
+    R.close()
+    return res, outs
+
+
+def h(t):
+    return t.half().float()
+
+
+CONV_CASES = [
+    # B, H, W, cin, cout, k, stride, dil, relu, residual, variant, in_extra_ch
+    (2, 24, 40, 64, 64, 3, 1, 1, True, True, 0, 0),        # v1 BN=64, residual
+    (1, 13, 21, 128, 128, 3, 1, 1, True, False, 0, 64),     # ragged M (273 px), input slice of a wider tensor
+    (2, 16, 24, 64, 128, 3, 2, 1, False, False, 0, 0),      # stride 2
+    (1, 12, 20, 256, 64, 1, 1, 1, True, False, 0, 0),       # 1x1
+    (1, 20, 36, 64, 256, 3, 1, 6, True, False, 0, 0),       # dilation 6 (head conv)
+    (3, 24, 40, 64, 256, 3, 1, 1, True, True, 2, 0),        # mfma256, ragged M (2880 = 11.25 tiles), residual
+    (1, 16, 20, 128, 512, 3, 1, 6, False, False, 2, 0),     # mfma256, NT=2, single partial tile... M=320
+    (2, 16, 24, 16, 16, 3, 1, 1, True, False, 3, 0),        # smallc 16->16
+    (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
+    (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
+    (1, 9, 13, 32, 64, 1, 1, 1, False, False, 3, 0),        # smallc 1x1
+    (2, 16, 24, 16, 16, 3, 1, 1, True, True, 1, 0),         # direct dot2 kernel (kept as a variant), residual
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_kernels_vs_torch(case):
+    B, H, W, cin, cout, k, stride, dil, relu, use_res, variant, extra = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    pad = dil * (k - 1) // 2
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt = P.tensor(H, W, cin + extra, max(pad, 1))
+    xs = P.sub(xt, extra, cin)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    yt = P.tensor(Ho, Wo, cout + 8, 1)
+    ys = P.sub(yt, 8, cout)
+    rs = P.tensor(Ho, Wo, cout, 0) if use_res else None
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    P.conv(xs, ys, w, b, stride=stride, dil=dil, relu=relu, res=rs, name='t')
+    P.ops[-1]['variant'] = variant
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    feeds = [(xs, x)]
+    if use_res:
+        r = rng.standard_normal((B, cout, Ho, Wo)).astype(np.float32)
+        feeds.append((rs, r))
+    (got,), _ = _run(P, feeds, [ys])
+    ref = F.conv2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), torch.from_numpy(b), stride, pad, dil)
+    if use_res:
+        ref = ref + h(torch.from_numpy(r))
+    if relu:
+        ref = ref.relu()
+    ref = h(ref).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 10, 0), (1, 12, 40, 0), (4, 24, 80, 2), (32, 12, 40, 2)])
+def test_deconv_phases_vs_torch(shape):
+    B, H, W, variant = shape
+    rng = np.random.default_rng(B * 1000 + H)
+    P = plan_mod.Plan(B, H * 8, W * 8)
+    xt = P.tensor(H, W, 256, 1)
+    yt = P.tensor(2 * H, 2 * W, 256, 0)
+    w = (rng.standard_normal((256, 256, 4, 4)) / 32).astype(np.float32)
+    P.deconv(xt, yt, w, name='up')
+    P.ops[-1]['variant'] = variant
+    x = rng.standard_normal((B, 256, H, W)).astype(np.float32)
+    (got,), _ = _run(P, [(xt, x)], [yt])
+    ref = h(F.conv_transpose2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), None, 2, 1)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('k,stride,pad', [(2, 2, 0), (3, 2, 1)])
+def test_maxpool_vs_torch(k, stride, pad):
+    rng = np.random.default_rng(k)
+    B, H, W, C = 2, 16, 24, 64
+    P = plan_mod.Plan(B, H, W)
+    xt = P.tensor(H, W, C + 16, 1)
+    yt = P.tensor(H // 2, W // 2, C, 0)
+    P.maxpool(P.sub(xt, 16, C), yt, k, stride, pad)
+    x = np.abs(rng.standard_normal((B, C, H, W))).astype(np.float32)        # post-ReLU inputs
+    (got,), _ = _run(P, [(P.sub(xt, 16, C), x)], [yt])
+    ref = F.max_pool2d(h(torch.from_numpy(x)), k, stride, pad).numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_softmax_fuse_with_peaked_inputs():
+    """z + sum_i u_i * softmax_HW(u_i) with large peaks (where the softmax term is not negligible)."""
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 12, 20
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    z0 = P.tensor(H, W, 256, 0)
+    us = [P.tensor(H, W, 256, p) for p in (0, 1, 0)]
+    z = P.tensor(H, W, 256, 6)
+    P.softmax_fuse(z0, z, us)
+    zin = rng.standard_normal((B, 256, H, W)).astype(np.float32)
+    uin = [(rng.standard_normal((B, 256, H, W)) * s).astype(np.float32) for s in (1.0, 3.0, 6.0)]
+    for u in uin:
+        u[:, :, 3, 4] += 9.0
+    (got,), _ = _run(P, [(z0, zin)] + list(zip(us, uin)), [z])
+    ref = h(torch.from_numpy(zin))
+    for u in uin:
+        t = h(torch.from_numpy(u))
+        ref = ref + t * torch.softmax(t.view(B, 256, -1), -1).view(B, 256, H, W)
+    ref = h(ref).numpy()
+    np.testing.assert_allclose(got, ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max())
+
+
+def test_stem_and_headout_vs_torch():
+    rng = np.random.default_rng(9)
+    B, H, W = 2, 32, 64
+    # stem 7x7 s1 3->16 and s2 3->64 straight from the fp32 NCHW image
+    for cout, stride in ((16, 1), (64, 2)):
+        P = plan_mod.Plan(B, H, W)
+        yt = P.tensor(H // stride, W // stride, cout, 1)
+        w = (rng.standard_normal((cout, 3, 7, 7)) / 12).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        P.stem_mfma(yt, w, b, stride)
+        x = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+        (got,), _ = _run(P, [], [yt], x_img=x)
+        ref = h(F.conv2d(h(x), h(torch.from_numpy(w)), torch.from_numpy(b), stride, 3).relu()).numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    # the four logit convs (halo-tile kernel), sizes that are not multiples of the 8x32 tile
+    for (Hh, Wh) in ((8, 40), (11, 37), (16, 64)):
+        P = plan_mod.Plan(B, Hh * 4, Wh * 4)
+        ht = P.tensor(Hh, Wh, 1024, 1)
+        ws = [(rng.standard_normal((c, 256, 3, 3)) / 48).astype(np.float32) for c in (3, 16, 2, 2)]
+        bs = [rng.standard_normal(c).astype(np.float32) for c in (3, 16, 2, 2)]
+        P.headout(ht, ws, bs)
+        x = rng.standard_normal((B, 1024, Hh, Wh)).astype(np.float32)
+        _, outs = _run(P, [(ht, x)], [])
+        for g, (w, b) in enumerate(zip(ws, bs)):
+            c = w.shape[0]
+            got = outs[g][:B * c * Hh * Wh].view(B, c, Hh, Wh).cpu().numpy()
+            ref = F.conv2d(h(torch.from_numpy(x[:, g * 256:(g + 1) * 256])), h(torch.from_numpy(w)), torch.from_numpy(b), 1, 1).numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+def test_resnet34_stage_parity():
+    import rtm3d_amd
+    from rtm3d_amd import weights
+    from oracle import rtm3d_ref
+    bb = 'RESNET-34'
+    sd = weights.synth_state_dict(bb, 2, 'trained', heat_bias=-3.0)
+    cfg = rtm3d_amd.kitti_config(bb)
+    m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
+    m.load_state_dict(sd)
+    x = weights.synth_images(1, 64, 128, seed=3)
+    logits = m.forward_logits(x.cuda())
+    _, lref = rtm3d_ref.model_forward(x, sd, bb)
+    for a, b in zip(logits, lref):
+        assert (a.cpu() - b).abs().max().item() < 0.03 * max(1.0, b.abs().max().item())
