@@ -37,6 +37,14 @@ struct LbWaveMem {
 
 struct LbWaveK { double k00, k02, k11, k12; };
 
+// value of `v` in lane `src` (src wave-uniform) -> every lane, through v_readlane (no LDS round trip)
+__device__ static inline double lbw_bcast(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
 // f (returned, identical in every lane) and g (-> w->g) at w->x.
 __device__ static inline double lbw_fg(LbWaveMem* w, const LbWaveK& K, int lane) {
     const int c = lane >> 3, i = lane & 7;
@@ -122,36 +130,45 @@ __device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
     return 0;
 }
 
-// U' x = b, single right-hand side in LDS (length n <= 64): lane j owns b[j] and its partial sum.
+// U' x = b, single right-hand side in LDS (length n <= 64): lane j owns b[j] and its partial sum; the
+// pivot value travels by v_readlane (no LDS write/read pair, no barrier inside the loop).
 __device__ static inline int lbw_trsv_ut(const double* a, int lda, int n, double* b, double* bc, int lane) {
+    (void)bc;
+    const bool act = lane < n;
+    const int col = (act ? lane : 0) * lda;
     double dot = 0.0;
-    double bj = lane < n ? b[lane] : 0.0;
+    double bj = act ? b[lane] : 0.0;
+    double anext = a[col], dnext = a[0];
     for (int k = 0; k < n; ++k) {
-        const double akk = a[k * lda + k];
+        const double akk = dnext, ak = anext;
+        if (k + 1 < n) { anext = a[col + k + 1]; dnext = a[(k + 1) * lda + k + 1]; }   // prefetch next step's operands
         if (akk == 0.0) return k + 1;
-        if (lane == k) { bj = (bj - dot) / akk; bc[0] = bj; }
-        WSYNC();
-        const double bk = bc[0];
-        if (lane > k && lane < n) dot += a[lane * lda + k] * bk;
-        WSYNC();
+        const double mine = (bj - dot) / akk;
+        if (lane == k) bj = mine;
+        const double bk = lbw_bcast(bj, k);
+        if (lane > k && act) dot += ak * bk;
     }
-    if (lane < n) b[lane] = bj;
+    if (act) b[lane] = bj;
     WSYNC();
     return 0;
 }
 // U x = b (column-oriented back substitution, same update order as the scalar version)
 __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double* b, double* bc, int lane) {
-    double bk = lane < n ? b[lane] : 0.0;
+    (void)bc;
+    const bool act = lane < n;
+    const int row = act ? lane : 0;
+    double bk = act ? b[lane] : 0.0;
+    double anext = a[(n - 1) * lda + row], dnext = a[(n - 1) * lda + n - 1];
     for (int j = n - 1; j >= 0; --j) {
-        const double ajj = a[j * lda + j];
+        const double ajj = dnext, aj = anext;
+        if (j > 0) { anext = a[(j - 1) * lda + row]; dnext = a[(j - 1) * lda + j - 1]; }
         if (ajj == 0.0) return j + 1;
-        if (lane == j) { bk = bk / ajj; bc[0] = bk; }
-        WSYNC();
-        const double tmp = -bc[0];
-        if (lane < j) bk += tmp * a[j * lda + lane];
-        WSYNC();
+        const double mine = bk / ajj;
+        if (lane == j) bk = mine;
+        const double tmp = -lbw_bcast(bk, j);
+        if (lane < j) bk += tmp * aj;
     }
-    if (lane < n) b[lane] = bk;
+    if (act) b[lane] = bk;
     WSYNC();
     return 0;
 }
