@@ -57,13 +57,6 @@ int rtm3d_tensor_upload(rtm3d_ctx* ctx, int id, int c0, int C, const float* h_nc
 /* Device blob (packed weights / folded biases).  Copies `bytes` from host; returns blob id.      */
 int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t bytes, int* id);
 
-/* First layer: direct KxK convolution of the caller's fp32 NCHW image (Cin = 3) + folded BN +
- * ReLU, written as padded NHWC fp16.  Replaces models/nets/dla.py:259-268 (7x7 s1 3->16) and
- * models/nets/resnet.py:124-126 (7x7 s2 3->64).
- * weights blob: fp32 [ky][kx][cin][cout]; bias blob: fp32 [cout].                                */
-int rtm3d_op_stem(rtm3d_ctx* ctx, int out_tensor, int ksize, int stride, int pad, int cout,
-                  int w_blob, int bias_blob);
-
 /* Copy the caller's fp32 NCHW (B,3,H,W) image into a 4-channel padded NHWC fp16 tensor (4th channel
  * zero, border >= 4): operand layout of the register-direct MFMA stem (kernel = 3 with cin = 4).      */
 int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor);

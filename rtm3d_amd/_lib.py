@@ -43,7 +43,6 @@ SIGNATURES = {
     'rtm3d_tensor_download': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'rtm3d_tensor_upload': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'rtm3d_blob_create': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int)]),
-    'rtm3d_op_stem': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_input_nhwc4': (c_int, [c_void_p, c_int]),
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
     'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),

@@ -94,7 +94,5 @@ bool conv_smallc_supported(int cin, int cout, int ntaps);
 hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s);
 hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStream_t s);
 bool conv_direct_supported(int cin, int cout, int ntaps);
-hipError_t launch_stem(const StemKArgs& a, int ksize, int cout, hipStream_t s);
-bool stem_supported(int ksize, int cout);
 hipError_t launch_maxpool(const PoolKArgs& a, hipStream_t s);
 hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s);

@@ -1,5 +1,6 @@
-// Direct convolutions for the layers the matrix cores cannot tile: the 3-channel stem and the
-// 16/32-channel layers at full / half resolution (DLA base_layer, level0, level1, level2 entry).
+// Direct (VALU) convolutions for the 16/32-channel layers at full / half resolution (DLA level0, level1,
+// level2 entry).  Kept as kernel variant 1: the register-direct MFMA kernels of conv_smallc.hip are the
+// default for these layers; this form is the cross-check and the fallback for residual epilogues.
 // These layers are HBM-bound (72-124 FLOP/B), so the design goal is
 // coalesced NHWC traffic, not MFMA: one thread owns one output pixel and all COUT accumulators,
 // weights are wave-uniform and come through the scalar cache (s_load), the inner product uses
@@ -83,63 +84,6 @@ hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStre
         hipLaunchKernelGGL((conv_direct_kernel<32, 64, 9>), grid, block, 0, s, a);
     else if (a.cin == 32 && a.cout == 64 && a.ntaps == 1)
         hipLaunchKernelGGL((conv_direct_kernel<32, 64, 1>), grid, block, 0, s, a);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------ stem
-// fp32 NCHW image -> KSxKS conv (3 input channels) + folded BN + ReLU -> padded NHWC fp16.
-template <int KS, int COUT>
-__global__ __launch_bounds__(256) void stem_kernel(const StemKArgs a) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const int M = a.B * a.Ho * a.Wo;
-    if (m >= M) return;
-    const int n = m / (a.Ho * a.Wo), rem = m - n * (a.Ho * a.Wo);
-    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-    const float* __restrict__ w = a.wgt;
-    float acc[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-    const size_t plane = (size_t)a.H * a.W;
-    const float* ib = a.in + (size_t)n * 3 * plane;
-#pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {
-        const int iy = oy * a.stride - a.pad + ky;
-        const bool yok = (iy >= 0) && (iy < a.H);
-#pragma unroll 1
-        for (int kx = 0; kx < KS; ++kx) {
-            const int ix = ox * a.stride - a.pad + kx;
-            const bool ok = yok && (ix >= 0) && (ix < a.W);
-            const size_t off = ok ? ((size_t)iy * a.W + ix) : 0;
-            const float* wt = w + (ky * KS + kx) * 3 * COUT;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = ok ? ib[ci * plane + off] : 0.f;
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wt[ci * COUT + c], acc[c]);
-            }
-        }
-    }
-    f16* op = a.out + ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C;
-#pragma unroll
-    for (int c8 = 0; c8 < COUT / 8; ++c8) {
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf(acc[c8 * 8 + e] + a.bias[c8 * 8 + e], 0.f);
-        *(f16x8*)(op + c8 * 8) = o;
-    }
-}
-
-bool stem_supported(int ksize, int cout) { return ksize == 7 && (cout == 16 || cout == 64); }
-
-hipError_t launch_stem(const StemKArgs& a, int ksize, int cout, hipStream_t s) {
-    const int M = a.B * a.Ho * a.Wo;
-    dim3 grid((M + 255) / 256), block(256);
-    if (ksize == 7 && cout == 16)
-        hipLaunchKernelGGL((stem_kernel<7, 16>), grid, block, 0, s, a);
-    else if (ksize == 7 && cout == 64)
-        hipLaunchKernelGGL((stem_kernel<7, 64>), grid, block, 0, s, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

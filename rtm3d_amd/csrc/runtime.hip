@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_STEM, OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -145,29 +145,6 @@ static void* get_blob(rtm3d_ctx* ctx, int id, size_t* bytes) {
     if (id < 0 || id >= (int)ctx->blobs.size()) return nullptr;
     if (bytes) *bytes = ctx->blob_bytes[id];
     return ctx->blobs[id];
-}
-
-extern "C" int rtm3d_op_stem(rtm3d_ctx* ctx, int out_tensor, int ksize, int stride, int pad, int cout,
-                             int w_blob, int bias_blob) {
-    Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
-    if (!o) RT_FAIL("op_stem: bad output tensor");
-    if (!stem_supported(ksize, cout) || o->C != cout) RT_FAIL("op_stem: unsupported ksize=%d cout=%d (tensor C=%d)", ksize, cout, o->C);
-    size_t wb = 0, bb = 0;
-    const float* w = (const float*)get_blob(ctx, w_blob, &wb);
-    const float* b = (const float*)get_blob(ctx, bias_blob, &bb);
-    if (!w || !b || wb != (size_t)ksize * ksize * 3 * cout * 4 || bb != (size_t)cout * 4) RT_FAIL("op_stem: weight/bias blob size mismatch");
-    Op op;
-    op.kind = OP_STEM; op.name = "stem_conv";
-    StemKArgs& a = op.stem;
-    a.in = nullptr; a.wgt = w; a.bias = b; a.out = o->base;
-    a.B = o->B; a.Ho = o->H; a.Wo = o->W; a.stride = stride; a.pad = pad;
-    a.H = o->H * stride; a.W = o->W * stride;
-    a.out_Hp = o->Hp; a.out_Wp = o->Wp; a.out_C = o->C; a.out_P = o->P;
-    op.stem_cout = cout; op.ksize = ksize;
-    op.flops = 2.0 * o->B * o->H * o->W * (double)ksize * ksize * 3 * cout;
-    op.bytes = (double)o->B * (3.0 * a.H * a.W * 4 + (double)o->H * o->W * cout * 2);
-    ctx->ops.push_back(op);
-    return 0;
 }
 
 extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
@@ -367,11 +344,6 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
 static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_out[4]) {
     hipError_t e = hipSuccess;
     switch (op.kind) {
-        case OP_STEM: {
-            StemKArgs a = op.stem; a.in = d_in;
-            e = launch_stem(a, op.ksize, op.stem_cout, s);
-            break;
-        }
         case OP_CONV_MFMA: {
             ConvKArgs a = op.conv;
             if (op.epi_nchw) a.out = d_out[op.out_slot];

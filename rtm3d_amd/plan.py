@@ -4,7 +4,7 @@ Orchestration only (BASELINE north_star: "host code stays Python for weight load
 orchestration").  ``build_plan`` walks the architecture once and emits a small IR:
 
   tensors : padded NHWC fp16 activations  {H, W, C, pad}
-  ops     : stem | conv | maxpool | softmax   with BatchNorm already folded into weights/bias
+  ops     : input4 | conv | headout | maxpool | softmax   with BatchNorm already folded into weights/bias
 
 ``realize`` packs the weights for the chosen kernel and records the plan into a runtime context
 through the C ABI.  The IR is plain numpy so the wiring (channel slices instead of torch.cat,
@@ -114,13 +114,6 @@ class Plan(object):
         assert inp.C == out.C
         self.ops.append({'op': 'maxpool', 'name': name, 'inp': inp, 'out': out, 'k': k, 'stride': stride, 'pad': pad})
 
-    def stem(self, out, w, bias, stride, name=''):
-        cout, cin, k, _ = w.shape
-        assert cin == 3 and out.C == cout and out.coff == 0
-        self.ops.append({'op': 'stem', 'name': name, 'out': out, 'k': k, 'stride': stride, 'pad': (k - 1) // 2,
-                         'cout': cout, 'w': np.ascontiguousarray(w.transpose(2, 3, 1, 0)).astype(np.float32),
-                         'bias': np.asarray(bias, np.float32)})
-
     def input_nhwc4(self, out, name='input'):
         """fp32 NCHW image -> 4-channel padded NHWC fp16 tensor (4th channel zero)."""
         assert out.C == 4 and out.coff == 0 and self.tensors[out.tid]['pad'] >= 4
@@ -155,9 +148,6 @@ class Plan(object):
             elif op['op'] == 'headout':
                 H, W = self.dims(op['inp'])
                 f += 2.0 * self.B * H * W * 9 * 256 * sum(w.shape[0] for w in op['w'])
-            elif op['op'] == 'stem':
-                H, W = self.dims(op['out'])
-                f += 2.0 * self.B * H * W * op['k'] * op['k'] * 3 * op['cout']
         return f
 
 
@@ -443,10 +433,6 @@ class RealizedPlan(object):
         bid = ctypes.c_int()
         _lib.check(self.lib.rtm3d_blob_create(self.ctx, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, ctypes.byref(bid)), 'blob_create')
         return bid.value
-
-    def _op_stem(self, op):
-        _lib.check(self.lib.rtm3d_op_stem(self.ctx, self.tids[op['out'].tid], op['k'], op['stride'], op['pad'], op['cout'],
-                                          self._blob(op['w']), self._blob(op['bias'])), 'op_stem ' + op['name'])
 
     def _op_conv(self, op):
         d = _lib.ConvDesc()

@@ -23,13 +23,7 @@ def run_plan(plan, x_nchw, half=False):
         return bufs[s.tid], t['pad'], t['H'], t['W']
 
     for op in plan.ops:
-        if op['op'] == 'stem':
-            o = op['out']
-            w = torch.from_numpy(op['w']).permute(3, 2, 0, 1).contiguous()       # (co, ci, ky, kx)
-            y = torch.nn.functional.conv2d(x_nchw, w, torch.from_numpy(op['bias']), op['stride'], op['pad']).relu()
-            buf, P, H, W = view(o)
-            buf[:, P:P + H, P:P + W, o.coff:o.coff + o.C] = rnd(y.permute(0, 2, 3, 1))
-        elif op['op'] == 'input4':
+        if op['op'] == 'input4':
             o = op['out']
             buf, P, H, W = view(o)
             buf[:, P:P + H, P:P + W, 0:3] = rnd(x_nchw.permute(0, 2, 3, 1))
