@@ -90,10 +90,10 @@ typedef struct rtm3d_conv_desc {
 int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
 
 /* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
- * input = the 4 x 256-channel tensor written by the grouped head conv, outputs = rtm3d_forward's four
- * fp32 NCHW logit buffers with cout4[i] channels.  Weights: fp16 [head][tap][8 k-blocks][64 lanes][8]
+ * input = the nheads x 256-channel tensor written by the grouped head conv (nheads = 4, or 2 for the
+ * "smoke" head table), outputs = rtm3d_forward's first nheads fp32 NCHW logit buffers, cout4[i] channels.  Weights: fp16 [head][tap][8 k-blocks][64 lanes][8]
  * (MFMA fragment order, 16 zero-padded rows per head), bias fp32 [head][16].                          */
-int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, const int* cout4);
+int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4);
 
 /* Max pooling k x k / stride / pad over channel slice, NHWC fp16 (models/nets/dla.py:170-172,
  * models/nets/resnet.py:128).  Inputs are post-ReLU (>= 0) so the zero border equals -inf padding. */
@@ -128,7 +128,9 @@ int rtm3d_probe_read(rtm3d_ctx* ctx, double* avg_ms, int* count);
  *   d_n[B] int32 count; d_cls[B*topk] int64; d_score[B*topk]; d_mproj[B*topk*2];
  *   d_verts[B*topk*16] (8 x (x,y)); d_bbox[B*topk*4] (x1,y1,x2,y2); rows >= n are untouched.
  * Order within an image: score descending, ties by ascending flat index (class-major).
- * d_workspace: at least rtm3d_decode2d_workspace_bytes(B, ncls, H, W) bytes.                      */
+ * d_workspace: at least rtm3d_decode2d_workspace_bytes(B, ncls, H, W) bytes.
+ * Peaks-only mode (d_offset_fr_main == d_main_offset == NULL, used by the "smoke" head table): only
+ * d_n, d_cls, d_score and d_mproj = integer key point (x, y) are written.                            */
 size_t rtm3d_decode2d_workspace_bytes(int B, int ncls, int H, int W);
 int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_fr_main,
                    const float* d_main_offset, int B, int ncls, int H, int W, float score_thresh,
@@ -154,6 +156,13 @@ int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_ver
 int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
                          const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
                          const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
+
+/* "smoke" head-table variant (its source is not in the reference snapshot: PARITY
+ * UNPINNED, published SMOKE formulation): closed-form box from the 8 regression channels at each key
+ * point of the peaks-only decode.  Outputs use the solver's layout x = [sin ry, cos ry, l, h, w, X, Y, Z]. */
+int rtm3d_decode_smoke(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls, const float* d_peak_xy,
+                       const float* d_reg, int H, int W, float down_sample, const double* d_K_per_image,
+                       const double* d_dim_ref, int ncls, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
 
 /* Stream restricted to `n_cus` compute units (hipExtStreamCreateWithCUMask) for the latency-bound
  * 3D decode of the two-stream pipeline; destroy with rtm3d_stream_destroy.                          */

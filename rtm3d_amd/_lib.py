@@ -45,7 +45,7 @@ SIGNATURES = {
     'rtm3d_blob_create': (c_int, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int)]),
     'rtm3d_op_input_nhwc4': (c_int, [c_void_p, c_int]),
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
-    'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_forward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
@@ -58,6 +58,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_decode3d': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
+    'rtm3d_decode_smoke': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_stream_create_cumask': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
     'rtm3d_stream_destroy': (c_int, [c_void_p]),
     'rtm3d_decode3d_scalar': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

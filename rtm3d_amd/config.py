@@ -54,7 +54,8 @@ def _defaults():
     c.DATASET = CfgNode(OBJs=['Car', 'Pedestrian', 'Cyclist'], MEAN=[0.485, 0.456, 0.406], STD=[0.229, 0.224, 0.225],
                         VERTEX_OFFSET_INFER=[0.75, 0.57])
     c.MODEL = CfgNode(BACKBONE='DLA-34', DOWN_SAMPLE=4., OUT_CHANNELS=256,
-                      KFNs=['level2', 'level3', 'level4', 'level5'], HEADER_NUM_CONV=2)
+                      KFNs=['level2', 'level3', 'level4', 'level5'], HEADER_NUM_CONV=2,
+                      HEAD_VARIANT='rtm3d')   # 'smoke': head-table variant, see rtm3d_amd/weights.py
     c.DETECTOR = CfgNode(CHECKPOINT='./weights/DLA-34/model_0000004.pt', SCORE_THRESH=0.5, TOPK_CANDIDATES=30,
                          NMS_THRESH_TEST=0.5)
     return c

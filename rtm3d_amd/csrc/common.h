@@ -80,6 +80,7 @@ struct HeadOutArgs {
     const float* bias;      // [head][16]
     float* out[4];          // fp32 NCHW logits per head
     int cout[4];
+    int nheads;
     int B, H, W;
     int in_Hp, in_Wp, in_C, in_P;
     int tiles_x, tiles_y;

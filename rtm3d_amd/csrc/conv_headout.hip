@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_headout_kernel(const HeadOutArgs a) 
 }
 
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s) {
-    dim3 grid(a.B * a.tiles_y * a.tiles_x, 4, 1), block(256);
+    dim3 grid(a.B * a.tiles_y * a.tiles_x, a.nheads, 1), block(256);
     hipLaunchKernelGGL(conv_headout_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ float sigmoid_aten(float x, bool vector) {
 
 __global__ __launch_bounds__(D2_THREADS) void decode2d_kernel(
     const float* __restrict__ main_kf, const float* __restrict__ offs, const float* __restrict__ moff,
-    int ncls, int H, int W, float thresh, int topk, float down,
+    int ncls, int H, int W, float thresh, int topk, float down, int mode,
     float* __restrict__ ws_sig, unsigned long long* __restrict__ ws_cand,
     int32_t* __restrict__ out_n, int64_t* __restrict__ out_cls, float* __restrict__ out_score,
     float* __restrict__ out_mproj, float* __restrict__ out_verts, float* __restrict__ out_bbox) {
@@ -150,6 +150,14 @@ __global__ __launch_bounds__(D2_THREADS) void decode2d_kernel(
         const float score = __uint_as_float((unsigned)(key >> 32));
         const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         const int c = idx / HW, r = idx - c * HW, y = r / W, x = r - y * W;
+        if (mode == 1) {      // peaks only ("smoke" head table): class, score, integer key-point
+            const size_t row = (size_t)b * topk + rank;
+            out_cls[row] = (int64_t)c;
+            out_score[row] = score;
+            out_mproj[row * 2 + 0] = (float)x;
+            out_mproj[row * 2 + 1] = (float)y;
+            return;
+        }
         // sub-pixel offset: sigmoid_ over the contiguous (2, N) gather result (models/model.py:48)
         const int n2 = 2 * nsel;
         const int vend = (n2 / ATEN_VSTEP) * ATEN_VSTEP;
@@ -189,15 +197,70 @@ extern "C" int rtm3d_decode2d(void* stream, const float* d_main_kf, const float*
                               float* d_score, float* d_mproj, float* d_verts, float* d_bbox) {
     if (B <= 0 || ncls <= 0 || H <= 0 || W <= 0) { rt_set_error("decode2d: bad shape"); return 1; }
     if (topk < 1 || topk > D2_MAXK) { rt_set_error("decode2d: topk must be in [1,%d]", D2_MAXK); return 1; }
-    if (!d_workspace || !d_main_kf || !d_offset_fr_main || !d_main_offset) { rt_set_error("decode2d: null pointer"); return 1; }
+    const int mode = (d_offset_fr_main == nullptr && d_main_offset == nullptr) ? 1 : 0;     // peaks only
+    if (!d_workspace || !d_main_kf || (mode == 0 && (!d_offset_fr_main || !d_main_offset))) { rt_set_error("decode2d: null pointer"); return 1; }
     const size_t total = (size_t)B * ncls * H * W;
     // candidate keys first (8-byte aligned), then the sigmoid plane
     unsigned long long* cand = (unsigned long long*)(((uintptr_t)d_workspace + 7) & ~(uintptr_t)7);
     float* sig = (float*)(cand + total);
     hipLaunchKernelGGL(decode2d_kernel, dim3(B), dim3(D2_THREADS), 0, (hipStream_t)stream, d_main_kf, d_offset_fr_main,
-                       d_main_offset, ncls, H, W, score_thresh, topk, down_sample, sig, cand, d_n, d_cls, d_score,
+                       d_main_offset, ncls, H, W, score_thresh, topk, down_sample, mode, sig, cand, d_n, d_cls, d_score,
                        d_mproj, d_verts, d_bbox);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode2d launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "smoke" head-table variant.  The branch's source is not part of the
+// reference snapshot, so this decode follows the published SMOKE formulation (Liu et al. 2020) and its
+// parity is UNPINNED: 8 regression channels [dz, dxc, dyc, dh, dw, dl, sin a, cos a] at the key point,
+//   z = 28.01 + 16.32 dz;  (u, v) = down * (x + dxc, y + dyc);  (X, Y, Z) = K^-1 (u z, v z, z)
+//   (h, w, l) = dim_ref[cls] * exp(dh, dw, dl)
+//   alpha = atan(sin / (cos + 1e-7)) -+ pi/2 (cos >= 0: -, else +);  ry = alpha + atan2(X, Z) wrapped to (-pi, pi]
+// One lane per slot; results in the layout of the L-BFGS-B solver: x = [sin ry, cos ry, l, h, w, X, Y, Z].
+__global__ __launch_bounds__(256) void smoke_decode_kernel(int B, int topk, const int32_t* __restrict__ n_per_image,
+                                                           const int64_t* __restrict__ cls, const float* __restrict__ peak,
+                                                           const float* __restrict__ reg, int H, int W, float down,
+                                                           const double* __restrict__ K, const double* __restrict__ dim_ref,
+                                                           int ncls, double* __restrict__ x_out, double* __restrict__ f_out,
+                                                           int32_t* __restrict__ nit, int32_t* __restrict__ status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * topk) return;
+    const int b = i / topk;
+    if (i - b * topk >= n_per_image[b]) { status[i] = -1; return; }
+    const int px = (int)peak[(size_t)i * 2], py = (int)peak[(size_t)i * 2 + 1];
+    const float* rp = reg + (size_t)b * 8 * H * W + (size_t)py * W + px;
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = (double)rp[(size_t)k * H * W];
+    int c = (int)cls[i];
+    c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
+    const double* Kb = K + (size_t)b * 9;
+    const double z = 28.01 + 16.32 * r[0];
+    const double u = (double)down * ((double)px + r[1]), v = (double)down * ((double)py + r[2]);
+    const double X = (u - Kb[2]) * z / Kb[0], Y = (v - Kb[5]) * z / Kb[4];
+    const double h = dim_ref[c * 3 + 0] * exp(r[3]), w = dim_ref[c * 3 + 1] * exp(r[4]), l = dim_ref[c * 3 + 2] * exp(r[5]);
+    const double PI = 3.14159265358979323846;
+    double alpha = atan(r[6] / (r[7] + 1e-7));
+    alpha += (r[7] >= 0.0) ? -0.5 * PI : 0.5 * PI;
+    double ry = alpha + atan2(X, z);
+    if (ry > PI) ry -= 2.0 * PI;
+    if (ry < -PI) ry += 2.0 * PI;
+    double* xo = x_out + (size_t)i * 8;
+    xo[0] = sin(ry); xo[1] = cos(ry); xo[2] = l; xo[3] = h; xo[4] = w; xo[5] = X; xo[6] = Y; xo[7] = z;
+    f_out[i] = 0.0; nit[i] = 0; status[i] = 0;
+}
+
+extern "C" int rtm3d_decode_smoke(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls, const float* d_peak_xy,
+                                  const float* d_reg, int H, int W, float down_sample, const double* d_K_per_image,
+                                  const double* d_dim_ref, int ncls, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status) {
+    if (B <= 0 || topk <= 0 || H <= 0 || W <= 0 || ncls <= 0) { rt_set_error("decode_smoke: bad sizes"); return 1; }
+    if (!d_n || !d_cls || !d_peak_xy || !d_reg || !d_K_per_image || !d_dim_ref || !d_x || !d_fun || !d_nit || !d_status) {
+        rt_set_error("decode_smoke: null pointer"); return 1;
+    }
+    hipLaunchKernelGGL(smoke_decode_kernel, dim3((B * topk + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, topk, d_n, d_cls,
+                       d_peak_xy, d_reg, H, W, down_sample, d_K_per_image, d_dim_ref, ncls, d_x, d_fun, d_nit, d_status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode_smoke launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
 }

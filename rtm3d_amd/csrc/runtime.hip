@@ -262,26 +262,28 @@ extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
     return 0;
 }
 
-extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, const int* cout4) {
+extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     if (!in || !cout4) RT_FAIL("op_headout: bad arguments");
-    if (in->C != 1024 || in->P < 1) RT_FAIL("op_headout: input must be the 4 x 256 channel head tensor with a border >= 1");
+    if (nheads < 1 || nheads > 4) RT_FAIL("op_headout: nheads must be in [1,4]");
+    if (in->C != 256 * nheads || in->P < 1) RT_FAIL("op_headout: input must be the nheads x 256 channel head tensor with a border >= 1");
     size_t wb = 0, bb = 0;
     const f16* w = (const f16*)get_blob(ctx, w_blob, &wb);
     const float* b = (const float*)get_blob(ctx, bias_blob, &bb);
-    if (!w || !b || wb != (size_t)4 * 9 * 8 * 64 * 8 * sizeof(f16) || bb != 64 * sizeof(float)) RT_FAIL("op_headout: weight/bias blob size mismatch");
+    if (!w || !b || wb != (size_t)nheads * 9 * 8 * 64 * 8 * sizeof(f16) || bb != (size_t)nheads * 16 * sizeof(float)) RT_FAIL("op_headout: weight/bias blob size mismatch");
     Op op;
     op.kind = OP_HEADOUT; op.name = "conv3x3_headout_halo";
     HeadOutArgs& a = op.ho;
     memset(&a, 0, sizeof(a));
     a.in = in->base; a.wgt = w; a.bias = b;
     int csum = 0;
-    for (int i = 0; i < 4; ++i) { if (cout4[i] < 1 || cout4[i] > 16) RT_FAIL("op_headout: cout must be in [1,16]"); a.cout[i] = cout4[i]; csum += cout4[i]; }
+    for (int i = 0; i < nheads; ++i) { if (cout4[i] < 1 || cout4[i] > 16) RT_FAIL("op_headout: cout must be in [1,16]"); a.cout[i] = cout4[i]; csum += cout4[i]; }
+    a.nheads = nheads;
     a.B = in->B; a.H = in->H; a.W = in->W;
     a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_P = in->P;
     a.tiles_x = (in->W + 31) / 32; a.tiles_y = (in->H + 7) / 8;
     op.flops = 2.0 * in->B * in->H * in->W * 9.0 * 256.0 * csum;
-    op.bytes = (double)in->B * in->H * in->W * (1024.0 * 2 + csum * 4.0);
+    op.bytes = (double)in->B * in->H * in->W * (256.0 * nheads * 2 + csum * 4.0);
     ctx->ops.push_back(op);
     return 0;
 }
@@ -369,7 +371,7 @@ static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_ou
 
 extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
     if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward: null argument");
-    for (int i = 0; i < 4; ++i) if (!d_out_logits[i]) RT_FAIL("forward: null logits buffer %d", i);
+    if (!d_out_logits[0]) RT_FAIL("forward: null logits buffer 0");
     if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
     const int n = (int)ctx->ops.size();
     for (int i = 0; i < n; ++i) {

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from . import plan as plan_mod
-from .weights import parse_backbone, state_dict_spec, synth_state_dict
+from .weights import parse_backbone, state_dict_spec, synth_state_dict, head_table
 
 
 class _Namespace(object):
@@ -52,13 +52,16 @@ class Model(object):
         parse_backbone(self._backbone_name)
         if int(config.MODEL.OUT_CHANNELS) != 256 or int(config.MODEL.HEADER_NUM_CONV) != 2:
             raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256, HEADER_NUM_CONV=2')
+        # 'rtm3d' (reference main branch) | 'smoke' (head-table variant, SURVEY.md 8 a12: parity unpinned)
+        self._head_variant = config.MODEL.get('HEAD_VARIANT', 'rtm3d') if hasattr(config.MODEL, 'get') else getattr(config.MODEL, 'HEAD_VARIANT', 'rtm3d')
+        self._head_channels = [c for _, _, c in head_table(self._head_variant)]
         self.training = True                     # nn.Module default; detect.py:31 calls eval()
         self.export = False
         self._device = None
         self._plans = {}
         self._ws = {}
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
-        self._sd = synth_state_dict(self._backbone_name, seed=0, style='init')
+        self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant)
         self.backbone = _Namespace(self, 'backbone')
         self.kfpn_fusion = _Namespace(self, 'kfpn_fusion')
         self.detect_header = _Namespace(self, 'detect_header')
@@ -68,7 +71,7 @@ class Model(object):
         return OrderedDict(self._sd)
 
     def load_state_dict(self, state_dict, strict=True):
-        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name))
+        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name, self._head_variant))
         missing = [k for k in want if k not in state_dict]
         unexpected = [k for k in state_dict if k not in want]
         if strict and (missing or unexpected):
@@ -125,7 +128,7 @@ class Model(object):
         key = (B, H, W, device.index)
         p = self._plans.get(key)
         if p is None:
-            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W)
+            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
             self._plans[key] = p
@@ -147,8 +150,9 @@ class Model(object):
         dev = x.device
         plan = self._plan_for(B, H, W, dev)
         with torch.cuda.device(dev):
-            outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in (3, 16, 2, 2)]
-            plan.forward(torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), [o.data_ptr() for o in outs])
+            outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in self._head_channels]
+            ptrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
+            plan.forward(torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), ptrs)
         return tuple(outs)
 
     def forward(self, x):
@@ -160,11 +164,14 @@ class Model(object):
 
     def decode2d(self, pred_logits, out=None):
         """Fixed-size device results of the 2D decode (no host sync)."""
-        main_kf, offs, moff = pred_logits[0], pred_logits[1], pred_logits[2]
-        for t in (main_kf, offs, moff):
+        smoke = self._head_variant == 'smoke'
+        used = (pred_logits[0],) if smoke else (pred_logits[0], pred_logits[1], pred_logits[2])
+        for t in used:
             if not t.is_cuda:
                 raise RuntimeError('rtm3d_amd.Model.inference needs CUDA (ROCm) tensors; there is no CPU path')
-        main_kf, offs, moff = (t.contiguous().float() for t in (main_kf, offs, moff))
+        used = [t.contiguous().float() for t in used]
+        main_kf = used[0]
+        offs_ptr, moff_ptr = (0, 0) if smoke else (used[1].data_ptr(), used[2].data_ptr())   # NULL, NULL = peaks only
         B, K, H, W = main_kf.shape
         topk = int(self.config.DETECTOR.TOPK_CANDIDATES)
         dev = main_kf.device
@@ -178,7 +185,7 @@ class Model(object):
                 ws = torch.empty(int(lib.rtm3d_decode2d_workspace_bytes(B, K, H, W)), dtype=torch.uint8, device=dev)
                 self._ws[key] = ws
             _lib.check(lib.rtm3d_decode2d(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), main_kf.data_ptr(),
-                                          offs.data_ptr(), moff.data_ptr(), B, K, H, W,
+                                          offs_ptr, moff_ptr, B, K, H, W,
                                           float(self.config.DETECTOR.SCORE_THRESH), topk, float(self.config.MODEL.DOWN_SAMPLE),
                                           ws.data_ptr(), out.n.data_ptr(), out.cls.data_ptr(), out.score.data_ptr(),
                                           out.mproj.data_ptr(), out.verts.data_ptr(), out.bbox.data_ptr()), 'decode2d')
@@ -189,6 +196,8 @@ class Model(object):
         det = self.decode2d(pred_logits)
         B, topk = det.n.shape[0], det.topk
         n = det.n.cpu().tolist()                 # the only host synchronisation of the path
+        if self._head_variant == 'smoke':
+            return self._inference_smoke(pred_logits, det, n)
         clses, m_scores, m_projs, v_projs_regress, bboxes_2d = ([None] * B for _ in range(5))
         for i in range(B):
             if n[i] == 0:
@@ -198,9 +207,28 @@ class Model(object):
             v_projs_regress[i], bboxes_2d[i] = det.verts[s], det.bbox[s]
         return clses, m_scores, m_projs, v_projs_regress, bboxes_2d
 
+    def _inference_smoke(self, pred_logits, det, n):
+        """Head-table variant: per-image (classes, scores, key points x down_sample, 8 regression values)."""
+        B, topk = det.n.shape[0], det.topk
+        reg = pred_logits[1]
+        down = float(self.config.MODEL.DOWN_SAMPLE)
+        clses, m_scores, m_projs, regs = ([None] * B for _ in range(4))
+        for i in range(B):
+            if n[i] == 0:
+                continue
+            s = slice(i * topk, i * topk + n[i])
+            xy = det.mproj[s]
+            clses[i], m_scores[i], m_projs[i] = det.cls[s], det.score[s], down * xy
+            regs[i] = reg[i][:, xy[:, 1].long(), xy[:, 0].long()].t().contiguous()
+        return clses, m_scores, m_projs, regs
+
     def forward_dict(self, x):
         """Dict view of the eval outputs (offered in addition to the reference tuple)."""
-        (c, s, m, v, b), logits = self.eval().forward(x)
+        dets, logits = self.eval().forward(x)
+        if self._head_variant == 'smoke':
+            c, s, m, r = dets
+            return {'clses': c, 'm_scores': s, 'm_projs': m, 'regression': r, 'main_kf_logits': logits[0], 'regression_logits': logits[1]}
+        c, s, m, v, b = dets
         return {'clses': c, 'm_scores': s, 'm_projs': m, 'v_projs_regress': v, 'bboxes_2d': b,
                 'main_kf_logits': logits[0], 'offset_fr_main_logits': logits[1], 'main_offset_logits': logits[2],
                 'vertex_offset_logits': logits[3]}
@@ -209,9 +237,12 @@ class Model(object):
     def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0)):
         """forward + 2D decode + 3D decode, all stream-ordered on the device (no host sync).
         K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D)."""
-        from .model_utils import decode3d_slots
+        from .model_utils import decode3d_slots, decode_smoke_slots
         logits = self.forward_logits(x)
         det = self.decode2d(logits)
         dim_ref = dim_ref if dim_ref is not None else self.config.DETECTOR.dim_ref
-        boxes = decode3d_slots(det, K_per_image, dim_ref, ref_loc)
+        if self._head_variant == 'smoke':
+            boxes = decode_smoke_slots(det, logits[1], K_per_image, dim_ref, float(self.config.MODEL.DOWN_SAMPLE))
+        else:
+            boxes = decode3d_slots(det, K_per_image, dim_ref, ref_loc)
         return det, boxes, logits

@@ -68,6 +68,26 @@ def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0), out=Non
     return out
 
 
+def decode_smoke_slots(det, reg_logits, K_per_image, dim_ref, down_sample=4.0, out=None):
+    """Closed-form box decode of the "smoke" head-table variant (parity unpinned) over the
+    slots of a peaks-only decode2d; same Boxes3D layout as the optimiser."""
+    lib = _lib.load()
+    dev = det.n.device
+    B, topk = det.n.shape[0], det.topk
+    reg = reg_logits.contiguous().float()
+    K = torch.as_tensor(K_per_image, dtype=torch.float64, device=dev).reshape(B, 9).contiguous()
+    dim = dim_ref if isinstance(dim_ref, torch.Tensor) else torch.as_tensor(np.asarray(dim_ref, np.float64), device=dev)
+    dim = dim.to(dev, torch.float64).contiguous()
+    if out is None:
+        out = Boxes3D(B * topk, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rtm3d_decode_smoke(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, topk, det.n.data_ptr(),
+                                          det.cls.data_ptr(), det.mproj.data_ptr(), reg.data_ptr(), int(reg.shape[2]), int(reg.shape[3]),
+                                          float(down_sample), K.data_ptr(), dim.data_ptr(), int(dim.shape[0]), out.x.data_ptr(),
+                                          out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode_smoke')
+    return out
+
+
 def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_kernel=False):
     """Raw solver results for N objects: (x (N,8), fun (N,), nit (N,), status (N,)) as numpy."""
     lib = _lib.load()

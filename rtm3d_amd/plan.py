@@ -20,7 +20,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, HEADS
+from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, head_table
 
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
@@ -132,7 +132,7 @@ class Plan(object):
 
     def headout(self, inp, ws, biases, name='heads.out'):
         """The four final 3x3 convs (cout <= 16 each) in one halo-tile launch -> fp32 NCHW logits."""
-        assert inp.C == 1024 and inp.coff == 0 and len(ws) == 4
+        assert inp.coff == 0 and 1 <= len(ws) <= 4 and inp.C == 256 * len(ws)
         self.ops.append({'op': 'headout', 'name': name, 'inp': inp, 'w': [np.asarray(w, np.float32) for w in ws],
                          'bias': [np.asarray(b, np.float32) for b in biases]})
 
@@ -265,7 +265,7 @@ def _build_resnet(P, sd, H, W, depth, feat_out):
             inpl = pl
 
 
-def build_plan(state_dict, backbone, B, H, W):
+def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d'):
     """state_dict: reference key names -> torch tensors.  H, W multiples of 32."""
     kind, depth = parse_backbone(backbone)
     if H % 32 or W % 32:
@@ -315,16 +315,19 @@ def build_plan(state_dict, backbone, B, H, W):
     z = P.tensor(fh[0][0], fh[0][1], oc, 6, name='z')
     P.softmax_fuse(z0, z, us, name='kfpn_softmax_fuse')
 
-    # ---- heads (models/nets/header.py:13-46): d6 conv of all four branches fused into one 256->1024 conv
-    h1 = P.tensor(fh[0][0], fh[0][1], 4 * oc, 1, name='h1')
-    h2 = P.tensor(fh[0][0], fh[0][1], 4 * oc, 1, name='h2')
-    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in HEADS])
+    # ---- heads (models/nets/header.py:13-46): the d6 convs of all G branches fused into one 256->G*256 conv
+    heads = head_table(head_variant)
+    G = len(heads)
+    h1 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h1')
+    h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2')
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in heads])
     P.conv(z, h1, np.concatenate(ws, 0), np.concatenate(bs, 0), dil=6, relu=True, name='heads.conv_d6')
-    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in HEADS])
-    P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(4)], [P.sub(h2, g * oc, oc) for g in range(4)], ws, bs,
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in heads])
+    P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(G)], [P.sub(h2, g * oc, oc) for g in range(G)], ws, bs,
                    relu=True, name='heads.conv_d1')
-    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%s' % (seq, last)) for seq, last, _ in HEADS])
+    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%s' % (seq, last)) for seq, last, _ in heads])
     P.headout(h2, ws, bs, name='heads.out_convs')
+    P.head_channels = [c for _, _, c in heads]
     return P
 
 
@@ -394,8 +397,9 @@ def pack_smallc_weights(wt):
 
 def pack_headout_weights(ws, biases):
     """4 x (cout<=16, 256, 3, 3) -> fp16 [head][tap][chunk*2+kk][lane=fk*16+row][8], fp32 bias [head][16]."""
-    out = np.zeros((4, 9, 8, 4, 16, 8), np.float32)                    # head, tap, kblk, fk, row, j
-    bias = np.zeros((4, 16), np.float32)
+    G = len(ws)
+    out = np.zeros((G, 9, 8, 4, 16, 8), np.float32)                    # head, tap, kblk, fk, row, j
+    bias = np.zeros((G, 16), np.float32)
     for h, (w, b) in enumerate(zip(ws, biases)):
         co = w.shape[0]
         wt = w.reshape(co, 8, 4, 8, 9)                                  # cout, kblk(=cin/32), fk, j, tap
@@ -484,8 +488,8 @@ class RealizedPlan(object):
 
     def _op_headout(self, op):
         w, b = pack_headout_weights(op['w'], op['bias'])
-        co = (ctypes.c_int * 4)(*[x.shape[0] for x in op['w']])
-        _lib.check(self.lib.rtm3d_op_headout(self.ctx, self.tids[op['inp'].tid], self._blob(w), self._blob(b), co), 'op_headout')
+        co = (ctypes.c_int * 4)(*([x.shape[0] for x in op['w']] + [0] * (4 - len(op['w']))))
+        _lib.check(self.lib.rtm3d_op_headout(self.ctx, self.tids[op['inp'].tid], self._blob(w), self._blob(b), len(op['w']), co), 'op_headout')
 
     def _op_input4(self, op):
         _lib.check(self.lib.rtm3d_op_input_nhwc4(self.ctx, self.tids[op['out'].tid]), 'op_input_nhwc4')

@@ -25,6 +25,18 @@ DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
 RESNET_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
 HEADS = [('main_kf_header', 'main_kf_head', 3), ('offset_fr_main_header', 'offset_fr_main_head', 16),
          ('main_offset_header', 'main_offset_head', 2), ('vertex_offset_header', 'vertex_offset_head', 2)]
+# "smoke" head-table variant (the branch's source is NOT in the reference
+# snapshot -> parity unpinned): rtm3d's main key-point heat map + ONE regression branch with the 8
+# channels of the SMOKE paper [dz, dxc, dyc, dh, dw, dl, sin(alpha), cos(alpha)], same 3-conv stack.
+HEADS_SMOKE = [('main_kf_header', 'main_kf_head', 3), ('regression_header', 'regression_head', 8)]
+
+
+def head_table(variant='rtm3d'):
+    if variant in (None, 'rtm3d'):
+        return HEADS
+    if variant == 'smoke':
+        return HEADS_SMOKE
+    raise ValueError('unknown MODEL.HEAD_VARIANT %r' % (variant,))
 
 
 def parse_backbone(name):
@@ -82,7 +94,7 @@ def _dla_tree_spec(s, p, level, cin, cout, stride, level_root, root_dim=0):
         s.bn(p + '.project.1', cout)
 
 
-def state_dict_spec(backbone):
+def state_dict_spec(backbone, head_variant='rtm3d'):
     """Ordered [(key, shape, kind, meta)] identical to the reference ``state_dict()`` order."""
     kind, depth = parse_backbone(backbone)
     s = _Spec()
@@ -126,7 +138,7 @@ def state_dict_spec(backbone):
         for j in range(i):
             s.deconv('kfpn_fusion.fusion_up%d.%d.conv_tran' % (i + 2, j), oc)
     # models/nets/header.py:13-37
-    for seq, last, cout in HEADS:
+    for seq, last, cout in head_table(head_variant):
         p = 'detect_header.' + seq
         s.conv(p + '.0', oc, oc, 3, bias=True)
         s.bn(p + '.1', oc)
@@ -170,14 +182,14 @@ def _trained_gain(bkind, key):
     return g['conv']
 
 
-def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0):
+def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d'):
     """Deterministic synthetic weights (fp32 CPU tensors) under the reference key names."""
     assert style in ('init', 'trained')
     rng = np.random.Generator(np.random.PCG64(seed))
     bkind = parse_backbone(backbone)[0]
     sd = OrderedDict()
     bil = _bilinear_kernel(4)
-    for key, shape, kind, meta in state_dict_spec(backbone):
+    for key, shape, kind, meta in state_dict_spec(backbone, head_variant):
         if kind == 'conv':
             cout, cin, k, _ = shape
             fan_in, fan_out = cin * k * k, cout * k * k

@@ -56,7 +56,7 @@ def run_plan(plan, x_nchw, half=False):
         elif op['op'] == 'headout':
             i = op['inp']
             ibuf, Pi, Hi, Wi = view(i)
-            for h in range(4):
+            for h in range(len(op['w'])):
                 xin = ibuf[:, Pi - 1:Pi + Hi + 1, Pi - 1:Pi + Wi + 1, h * 256:(h + 1) * 256].permute(0, 3, 1, 2)
                 outs[h] = torch.nn.functional.conv2d(xin, rnd(torch.from_numpy(op['w'][h])), torch.from_numpy(op['bias'][h]))
         elif op['op'] == 'maxpool':

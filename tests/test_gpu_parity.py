@@ -276,3 +276,45 @@ def test_errors_are_loud(dev):
     lib = _lib.load()
     assert lib.rtm3d_decode2d(None, None, None, None, 1, 3, 8, 8, ctypes.c_float(0.4), 100, ctypes.c_float(4.0), None, None, None, None, None, None, None) != 0
     assert b'null' in lib.rtm3d_last_error()
+
+
+def test_smoke_head_variant_self_consistency(dev):
+    """SURVEY 8 a12 / BASELINE configs[4]: the smoke branch's source is not in the reference snapshot, so
+    this is a PARITY-UNPINNED regression check of the HIP path against the oracle's restatement of the
+    published SMOKE head layout (2 branches: heat map + 8 regression channels, closed-form box)."""
+    from oracle import smoke_ref
+    bb = 'DLA-34'
+    cfg = rtm3d_amd.kitti_config(bb)
+    cfg.MODEL.HEAD_VARIANT = 'smoke'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0, head_variant='smoke')
+    assert 'detect_header.regression_header.regression_head.weight' in sd and len(sd) == 321 - 2 * 16
+    m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
+    m.load_state_dict(sd)
+    x = weights.synth_images(2, 96, 160, seed=21)
+    K = np.tile(weights.synth_intrinsics(), (2, 1))
+    (clses, scores, mprojs, regs), logits = m(x.to(dev))
+    lref = smoke_ref.model_forward(x, sd, bb)
+    assert len(logits) == 2 and logits[1].shape == (2, 8, 24, 40)
+    for a, b in zip(logits, lref):
+        assert (a.cpu() - b).abs().max().item() < LOGIT_RTOL * max(1.0, b.abs().max().item())
+    # decode on the oracle's logits: key points bit-exact, boxes to fp64 libm accuracy
+    det, boxes, _ = None, None, None
+    from rtm3d_amd.model_utils import decode_smoke_slots
+    d = m.decode2d([l.to(dev) for l in lref])
+    bx = decode_smoke_slots(d, lref[1].to(dev), torch.as_tensor(K, device=dev), cfg.DETECTOR.dim_ref, 4.0)
+    ref = smoke_ref.decode(lref[0], lref[1], K, cfg.DETECTOR.dim_ref, 0.4, 100, 4.0)
+    n = d.n.cpu().numpy()
+    for b in range(2):
+        if ref[b] is None:
+            assert n[b] == 0
+            continue
+        k = len(ref[b]['cls'])
+        assert n[b] == k
+        np.testing.assert_array_equal(d.cls[b * 100:b * 100 + k].cpu().numpy(), ref[b]['cls'])
+        np.testing.assert_array_equal(d.score[b * 100:b * 100 + k].cpu().numpy(), ref[b]['score'])
+        np.testing.assert_array_equal(d.mproj[b * 100:b * 100 + k].cpu().numpy(), ref[b]['xy'])
+        np.testing.assert_allclose(bx.x[b * 100:b * 100 + k].cpu().numpy(), ref[b]['x8'], rtol=1e-9, atol=1e-9)
+        assert (bx.status[b * 100 + k:(b + 1) * 100] == -1).all()
+    # the fused device pipeline uses the same kernels
+    det, boxes, _ = m.detect3d(x.to(dev), torch.as_tensor(K, device=dev))
+    assert int(det.n.sum()) == int((boxes.status >= 0).sum())
