@@ -349,8 +349,12 @@ def choose_variant(cin, cout, M, groups, out_nchw):
     chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 1 = direct (small cin)."""
     if cin % 64:
         return 3 if cin in (4, 16, 32) else 1
-    if not out_nchw and cout % 256 == 0 and ((M + 255) // 256) * (cout // 256) * groups >= 512:
-        return 2
+    if not out_nchw and cout % 256 == 0:
+        # one workgroup per CU (256 CUs): at least two full rounds.  (A single nearly full round - DLA
+        # level4, 240 tiles - is 25 % faster per launch but loses 1.3 % end to end: early in the forward the
+        # 3D decode of the previous batch is still resident and cannot share a SIMD with this kernel.)
+        if ((M + 255) // 256) * (cout // 256) * groups >= 512:
+            return 2
     return 0
 
 
