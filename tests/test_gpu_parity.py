@@ -318,3 +318,49 @@ def test_smoke_head_variant_self_consistency(dev):
     # the fused device pipeline uses the same kernels
     det, boxes, _ = m.detect3d(x.to(dev), torch.as_tensor(K, device=dev))
     assert int(det.n.sum()) == int((boxes.status >= 0).sum())
+
+
+def test_config1_resnet18_bs8_device_decode_equals_host_decode(dev):
+    """BASELINE configs[1]: ResNet-18, bs=8, 384x1280, backbone+heads in HIP, decode on the host.
+    The host decode (oracle restatement of Model.inference) of the HIP logits and the device decode
+    kernel must agree bit for bit (same logits in, integer/fp32 arithmetic in the same order)."""
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-5.0)
+    m = make_model(bb, sd)
+    x = weights.synth_images(8, 384, 1280, seed=1234).to(dev)
+    dets, logits = m(x)
+    host = rtm3d_ref.inference([l.cpu() for l in logits], 0.4, 100, 4.0)
+    seen = 0
+    for b in range(8):
+        if host[0][b] is None:
+            assert dets[0][b] is None
+            continue
+        sc = host[1][b].numpy()
+        if len(np.unique(sc)) != len(sc):
+            continue
+        seen += len(sc)
+        for k in range(5):
+            np.testing.assert_array_equal(to_np(dets[k][b]), to_np(host[k][b]))
+    assert seen > 0
+
+
+def test_config2_dla34_bs32_full_size_properties(dev):
+    """BASELINE configs[2] at full size (bs=32, 384x1280): images are independent, so image b of the batch
+    must equal the same image run alone (bit-exact logits and detections), for a sample of b."""
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-6.0)
+    m = make_model(bb, sd)
+    x = weights.synth_images(32, 384, 1280, seed=1234).to(dev)
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (32, 1)), device=dev)
+    det, boxes, logits = m.detect3d(x, K)
+    torch.cuda.synchronize()
+    n = det.n.cpu().numpy()
+    assert n.sum() > 0 and n.max() <= 100
+    for b in (0, 13, 31):
+        d1, b1, l1 = m.detect3d(x[b:b + 1], K[b:b + 1])
+        for a, c in zip(logits, l1):
+            assert torch.equal(a[b:b + 1], c)
+        k = int(n[b])
+        assert int(d1.n.item()) == k
+        assert torch.equal(det.cls[b * 100:b * 100 + k], d1.cls[:k]) and torch.equal(det.verts[b * 100:b * 100 + k], d1.verts[:k])
+        assert torch.equal(boxes.x[b * 100:b * 100 + k], b1.x[:k])
