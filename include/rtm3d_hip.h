@@ -164,6 +164,14 @@ int rtm3d_decode_smoke(void* stream, int B, int topk, const int32_t* d_n, const 
                        const float* d_reg, int H, int W, float down_sample, const double* d_K_per_image,
                        const double* d_dim_ref, int ncls, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
 
+/* Input pipeline step in front of the path: letterbox an already resized uint8 HWC
+ * image (h x w x 3, channel order as loaded) into the H x W canvas, centred, border = the image's mean
+ * colour truncated to uint8 (datasets/dataset_reader.py:175-195), then Normalize/ToTensor/ToNCHW
+ * (preprocess/transforms.py:110-120,312-322) -> fp32 CHW at d_out_chw.  d_lut: fp32 [3][256] =
+ * float32((v/255. - mean[c]) / std[c]) computed in float64 like the reference; d_sums3: 3 x uint64 scratch. */
+int rtm3d_preprocess(void* stream, const uint8_t* d_img_hwc, int h, int w, float* d_out_chw, int H, int W,
+                     const float* d_lut, unsigned long long* d_sums3);
+
 /* Stream restricted to `n_cus` compute units (hipExtStreamCreateWithCUMask) for the latency-bound
  * 3D decode of the two-stream pipeline; destroy with rtm3d_stream_destroy.                          */
 int rtm3d_stream_create_cumask(int device, int n_cus, void** stream);
