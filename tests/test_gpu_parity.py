@@ -364,3 +364,32 @@ def test_config2_dla34_bs32_full_size_properties(dev):
         assert int(d1.n.item()) == k
         assert torch.equal(det.cls[b * 100:b * 100 + k], d1.cls[:k]) and torch.equal(det.verts[b * 100:b * 100 + k], d1.verts[:k])
         assert torch.equal(boxes.x[b * 100:b * 100 + k], b1.x[:k])
+
+
+def test_two_stream_pipeline_equals_serial_path(dev):
+    """The bench path (forward ∥ decode3d on two streams, double-buffered slots) returns exactly the records
+    of the serial path, for a sequence of different batches (exercises slot reuse and event ordering)."""
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    from rtm3d_amd import distributed as rdist
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5)
+    m = make_model(bb, sd)
+    B = 3
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), device=dev)
+    xs = [weights.synth_images(B, 64, 128, seed=100 + 7 * i).to(dev) for i in range(5)]
+    pipe = Detect3DPipeline(m, B, dev, gather=True)
+    ids = [pipe.submit(x, K) for x in xs[:2]]
+    got = {ids[0]: pipe.results(ids[0]).clone()}            # read slot 0 before it is reused
+    for x in xs[2:]:
+        i = pipe.submit(x, K)
+        got[i - 1] = pipe.results(i - 1).clone()
+        ids.append(i)
+    got[ids[-1]] = pipe.results(ids[-1]).clone()
+    pipe.drain()
+    for i, x in enumerate(xs):
+        det, boxes, _ = m.detect3d(x, K)
+        ref = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, 100, boxes)
+        torch.cuda.synchronize()
+        assert torch.equal(got[i], ref), i
+    recs = rdist.unpack_records(got[0])
+    assert len(recs) == B and all(r is None or r['verts'].shape[1:] == (8, 2) for r in recs)
