@@ -2,15 +2,15 @@
 // Replaces Model.inference / _obtain_main_proj2d / _obtain_offset_fr_main
 // (models/model.py:29-98,117-132) and nms_hm (utils/model_utils.py:17-26).
 //
-// One 1024-thread workgroup per image:
-//   A  sigmoid of the K*H*W heat-map logits -> workspace (L2 resident, 368 KB at 3x96x320)
-//   B  3x3 max with -inf border, keep s == max (all members of a plateau survive, like the
-//      reference), compact survivors with s > thresh as unique 64-bit keys
-//      (score bits << 32 | ~flat_index) -> candidate list
-//   C  exact radix select (8 passes x 8 bits) of the top-k-th key, gather keys >= it, rank them
-//      => order: score descending, ties by ascending flat (class-major) index
-//   D  one lane per detection: class/y/x from the flat index, 16-channel offset gather, sub-pixel
-//      sigmoid, vertices and 2D box in the reference's fp32 operation order.
+// Three launches:
+//   A  (grid over all B*K*H*W elements) sigmoid of the heat-map logits -> workspace (L2 resident)
+//   B  (same grid) 3x3 max with -inf border, keep s == max (all members of a plateau survive, like
+//      the reference), append survivors with s > thresh as unique 64-bit keys
+//      (score bits << 32 | ~flat_index) to the image's candidate list (global atomic counter)
+//   C+D (one 1024-thread workgroup per image) exact radix select (8 passes x 8 bits) of the top-k-th
+//      key, gather keys >= it, rank them => order: score descending, ties by ascending flat
+//      (class-major) index; then one lane per detection: class/y/x from the flat index, 16-channel
+//      offset gather, sub-pixel sigmoid, vertices and 2D box in the reference's fp32 operation order.
 //
 // Bit-exactness: the fp32 sigmoid reproduces what PyTorch-CPU computes: the vectorised path is
 // Sleef's expf_u10 polynomial (fma form) followed by an IEEE divide; elements that fall in the
@@ -59,49 +59,58 @@ __device__ __forceinline__ float sigmoid_aten(float x, bool vector) {
 #define ATEN_GRAIN 32768
 #define ATEN_VSTEP 32
 
+__global__ __launch_bounds__(256) void d2_sigmoid_kernel(const float* __restrict__ main_kf, float* __restrict__ sig, int total,
+                                                         int B, int* __restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) cnt[i] = 0;
+    if (i >= B * total) return;
+    const int local = i % total;
+    const int vec_end = (total < ATEN_GRAIN) ? (total / ATEN_VSTEP) * ATEN_VSTEP : total;
+    sig[i] = sigmoid_aten(main_kf[i], local < vec_end);
+}
+
+__global__ __launch_bounds__(256) void d2_nms_kernel(const float* __restrict__ sig_all, unsigned long long* __restrict__ cand_all,
+                                                     int* __restrict__ cnt, int B, int ncls, int H, int W, float thresh) {
+    const int HW = H * W, total = ncls * HW;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= B * total) return;
+    const int b = gi / total, i = gi - b * total;
+    const int c = i / HW, r = i - c * HW, y = r / W, x = r - y * W;
+    const float* pl = sig_all + (size_t)b * total + c * HW;
+    const float s = pl[r];
+    float mx = s;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            mx = fmaxf(mx, pl[yy * W + xx]);
+        }
+    }
+    if (mx == s && s > thresh) {
+        const int pos = atomicAdd(&cnt[b], 1);
+        cand_all[(size_t)b * total + pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    }
+}
+
 __global__ __launch_bounds__(D2_THREADS) void decode2d_kernel(
     const float* __restrict__ main_kf, const float* __restrict__ offs, const float* __restrict__ moff,
     int ncls, int H, int W, float thresh, int topk, float down, int mode,
-    float* __restrict__ ws_sig, unsigned long long* __restrict__ ws_cand,
+    const int* __restrict__ cnt, unsigned long long* __restrict__ ws_cand,
     int32_t* __restrict__ out_n, int64_t* __restrict__ out_cls, float* __restrict__ out_score,
     float* __restrict__ out_mproj, float* __restrict__ out_verts, float* __restrict__ out_bbox) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int HW = H * W, total = ncls * HW;
-    const float* hm = main_kf + (size_t)b * total;
-    float* sig = ws_sig + (size_t)b * total;
     unsigned long long* cand = ws_cand + (size_t)b * total;
 
     __shared__ int hist[256];
     __shared__ unsigned long long sel[D2_MAXK];
-    __shared__ int s_n, s_nsel, s_bin, s_cum;
+    __shared__ int s_nsel, s_bin, s_cum;
 
-    if (tid == 0) { s_n = 0; s_nsel = 0; }
-    // ---- A: sigmoid
-    const int vec_end = (total < ATEN_GRAIN) ? (total / ATEN_VSTEP) * ATEN_VSTEP : total;
-    for (int i = tid; i < total; i += D2_THREADS) sig[i] = sigmoid_aten(hm[i], i < vec_end);
+    if (tid == 0) s_nsel = 0;
     __syncthreads();
-    // ---- B: NMS + compaction
-    for (int i = tid; i < total; i += D2_THREADS) {
-        const int c = i / HW, r = i - c * HW, y = r / W, x = r - y * W;
-        const float* pl = sig + c * HW;
-        const float s = pl[r];
-        float mx = s;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                mx = fmaxf(mx, pl[yy * W + xx]);
-            }
-        }
-        if (mx == s && s > thresh) {
-            const int pos = atomicAdd(&s_n, 1);
-            cand[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-        }
-    }
-    __syncthreads();
-    const int n = s_n;
+    const int n = cnt[b];
     // ---- C: exact top-k by radix select on the unique 64-bit keys
     unsigned long long T = 0ull;
     if (n > topk) {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(D2_THREADS) void decode2d_kernel(
 extern void rt_set_error(const char* fmt, ...);
 
 extern "C" size_t rtm3d_decode2d_workspace_bytes(int B, int ncls, int H, int W) {
-    return (size_t)B * ncls * H * W * (sizeof(float) + sizeof(unsigned long long)) + 256;
+    return (size_t)B * ncls * H * W * (sizeof(float) + sizeof(unsigned long long)) + (size_t)B * sizeof(int) + 256;
 }
 
 extern "C" int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_fr_main,
@@ -203,8 +212,13 @@ extern "C" int rtm3d_decode2d(void* stream, const float* d_main_kf, const float*
     // candidate keys first (8-byte aligned), then the sigmoid plane
     unsigned long long* cand = (unsigned long long*)(((uintptr_t)d_workspace + 7) & ~(uintptr_t)7);
     float* sig = (float*)(cand + total);
+    int* cnt = (int*)(sig + total);
+    const int per_image = ncls * H * W;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(d2_sigmoid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_main_kf, sig, per_image, B, cnt);
+    hipLaunchKernelGGL(d2_nms_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sig, cand, cnt, B, ncls, H, W, score_thresh);
     hipLaunchKernelGGL(decode2d_kernel, dim3(B), dim3(D2_THREADS), 0, (hipStream_t)stream, d_main_kf, d_offset_fr_main,
-                       d_main_offset, ncls, H, W, score_thresh, topk, down_sample, mode, sig, cand, d_n, d_cls, d_score,
+                       d_main_offset, ncls, H, W, score_thresh, topk, down_sample, mode, cnt, cand, d_n, d_cls, d_score,
                        d_mproj, d_verts, d_bbox);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode2d launch: %s", hipGetErrorString(e)); return 1; }
