@@ -140,9 +140,13 @@ class Plan(object):
         self.ops.append({'op': 'softmax', 'name': name, 'z_in': z_in, 'z_out': z_out, 'us': list(us)})
 
     def total_flops(self):
+        """Algorithmic FLOPs of the REFERENCE graph (2 x MAC of its conv layers): composed 1x1 pairs count as
+        the two original layers, the NHWC4 stem as 3 input channels."""
         f = 0.0
         for op in self.ops:
-            if op['op'] == 'conv':
+            if op['op'] == 'conv' and 'ref_macs_per_px' in op:
+                f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['ref_macs_per_px']
+            elif op['op'] == 'conv':
                 cin = 3 if op['cin'] == 4 else op['cin']          # NHWC4 stem: the 4th channel is zero padding
                 f += 2.0 * self.B * op['Hm'] * op['Wm'] * op['groups'] * cin * len(op['taps'][0]) * op['cout']
             elif op['op'] == 'headout':
@@ -285,21 +289,33 @@ def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d'):
         _build_resnet(P, sd, H, W, depth, feat)
 
     # ---- neck (models/nets/keypoint_fpn_fusion.py:35-46)
+    # x[i-1] = proj_i(cat[up_i(head_i(x[i])), x[i-1]]) is only ever consumed by the next 1x1 `head` conv and
+    # there is no non-linearity in between, so proj followed by head is ONE linear map: the two 1x1 convs
+    # are composed on the host (fp64) into a single (256+C) -> 256 conv.  Same function, one rounding less,
+    # and the C-channel intermediate never touches HBM (these 1x1 layers are bandwidth-bound).
+    def compose(proj_key, head_key):
+        wp, bp = fold_bn(sd, proj_key)                      # (C, 256+C, 1, 1)
+        wh, bh = fold_bn(sd, head_key)                      # (256, C, 1, 1)
+        w2 = wh[:, :, 0, 0].astype(np.float64) @ wp[:, :, 0, 0].astype(np.float64)
+        b2 = wh[:, :, 0, 0].astype(np.float64) @ bp.astype(np.float64) + bh.astype(np.float64)
+        return w2.astype(np.float32)[:, :, None, None], b2.astype(np.float32)
+
     hs = [None] * 4
-    x_top = feat[3]
+    hs[3] = P.tensor(fh[3][0], fh[3][1], oc, 1, name='kfpn_h5')
+    w, b = fold_bn(sd, 'kfpn_fusion.kfpn_head5')
+    P.conv(feat[3], hs[3], w, b, name='kfpn_head5')
     for i in (3, 2, 1):
         L = i + 2
-        hs[i] = P.tensor(fh[i][0], fh[i][1], oc, 1, name='kfpn_h%d' % L)
-        w, b = fold_bn(sd, 'kfpn_fusion.kfpn_head%d' % L)
-        P.conv(x_top, hs[i], w, b, name='kfpn_head%d' % L)
         P.deconv(hs[i], P.sub(ncat[i - 1], 0, oc), _np(sd, 'kfpn_fusion.kfpn_up%d.conv_tran.weight' % L).astype(np.float32),
                  name='kfpn_up%d' % L)
-        x_top = P.tensor(fh[i - 1][0], fh[i - 1][1], fch[i - 1], 0, name='kfpn_p%d' % (L - 1))
-        w, b = fold_bn(sd, 'kfpn_fusion.kfpn_proj%d' % L)
-        P.conv(ncat[i - 1], x_top, w, b, name='kfpn_proj%d' % L)
+        w, b = compose('kfpn_fusion.kfpn_proj%d' % L, 'kfpn_fusion.kfpn_head%d' % (L - 1))
+        if i > 1:
+            hs[i - 1] = P.tensor(fh[i - 1][0], fh[i - 1][1], oc, 1, name='kfpn_h%d' % (L - 1))
+            P.conv(ncat[i - 1], hs[i - 1], w, b, name='kfpn_proj%d+head%d' % (L, L - 1))
+            P.ops[-1]['ref_macs_per_px'] = (oc + fch[i - 1]) * fch[i - 1] + fch[i - 1] * oc
     z0 = P.tensor(fh[0][0], fh[0][1], oc, 0, name='z0')
-    w, b = fold_bn(sd, 'kfpn_fusion.kfpn_head2')
-    P.conv(x_top, z0, w, b, name='kfpn_head2')
+    P.conv(ncat[0], z0, w, b, name='kfpn_proj3+head2')
+    P.ops[-1]['ref_macs_per_px'] = (oc + fch[0]) * fch[0] + fch[0] * oc
     # ---- fusion (keypoint_fpn_fusion.py:60-69): z = z0 + sum_i up^i(h_i) * softmax(up^i(h_i))
     us = []
     for i in (3, 2, 1):
