@@ -28,7 +28,7 @@
 #define SLOT_WA 2
 #define SLOT_WB 3
 
-template <int EPI>
+template <int RES>
 __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];   // + dummy slot for tail stages
     const int tid = threadIdx.x;
@@ -165,41 +165,313 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
 
     // ---------------------------------------------------------------- epilogue
+    // All loads (bias, residual) are issued before the first store and the stores form one
+    // dependency-free run: a load between two stores would make the compiler wait vmcnt(0), i.e. for
+    // the previous store's acknowledgement as well, and serialise 32 round trips per thread.
+    f32x4 bv[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            bv[j][c] = *(const f32x4*)(a.bias + g.bias_off + ntile * 256 + j * 128 + wc * 32 + c * 16 + fk * 4);
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+    const int cbase = ntile * 256 + wc * 32 + fk * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        size_t opix[4];
+        f16x4 rv[4][2][2];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int m = mtile * 256 + i * 128 + wp * 64 + p * 16 + frow;
-            if (m >= a.M) continue;
+            // rows past M were staged from pixel M-1 (see xoff), so they hold its result: storing them
+            // to its address again is a same-value write and keeps the epilogue branch-free
+            int m = mtile * 256 + i * 128 + wp * 64 + p * 16 + frow;
+            m = m < a.M ? m : a.M - 1;
             const int n = m / a.HmWm, rem = m - n * a.HmWm;
             const int y = rem / a.Wm, x = rem - y * a.Wm;
             const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
-            const size_t opix = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff;
-            const size_t rpix = a.res ? ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff : 0;
+            opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + cbase;
+            if (RES) {
+                const f16* rp = a.res + ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff + cbase;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) rv[p][j][c] = *(const f16x4*)(rp + j * 128 + c * 16);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const int c0 = ntile * 256 + j * 128 + wc * 32 + c * 16 + fk * 4;
-                    f32x4 v = acc[i][j][c][p];
-                    const f32x4 b = *(const f32x4*)(a.bias + g.bias_off + c0);
-                    v += b;
-                    if (a.res) {
-                        const f16x4 r = *(const f16x4*)(a.res + rpix + c0);
+                    f32x4 v = acc[i][j][c][p] + bv[j][c];
+                    if (RES) {
+                        const f16x4 r = rv[p][j][c];
                         v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
                     }
-                    if (a.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                    }
-                    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                    *(f16x4*)((f16*)a.out + opix + c0) = h;
+                    const f16x4 h = {(f16)fmaxf(v[0], lo), (f16)fmaxf(v[1], lo), (f16)fmaxf(v[2], lo), (f16)fmaxf(v[3], lo)};
+                    *(f16x4*)((f16*)a.out + opix[p] + j * 128 + c * 16) = h;
                 }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form (default when there is no residual operand and the K loop has >= 4 tiles).
+// One workgroup per CU walks its XCD's list of output tiles:
+//   * the half-tile DMA pipeline runs straight across tile boundaries: the last two K-tiles of a
+//     tile already stage the first two of the next one (descriptor "n"), so there is no prologue,
+//     no drain and no workgroup launch between tiles;
+//   * the bias vector sits in LDS (a VMEM load in the epilogue would make the compiler drain vmcnt);
+//     the epilogue is 16 global_store_dwordx4
+//     per thread (v_permlane16_swap pairs the two 16-channel MFMA tiles so a lane owns 8 consecutive
+//     channels) with no wait behind them: the first K-tile of the next tile runs its four phases
+//     with s_waitcnt vmcnt(8+16) (the 16 stores are younger than the DMA it needs);
+//   * pixel -> (image, row, column) uses a float-estimate division (quotients are tiny).
+// Measured (in-kernel stamps, bs=32): the one-tile kernel spends 1.8 us in its prologue, 5.4 us in
+// its epilogue and ~3.8 us between workgroups per tile.  That is 16 % of a 36-K-tile head tile but
+// 35-60 % of the 16- and 4-K-tile tiles of the transposed-conv phases and 1x1 convs, which is where
+// this form pays: -12 % and -25 % on those; the head convs stay at ~1.2 PFLOP/s in either form - on
+// non-zero data they run at the rate the chip's power management allows (1.9 GHz in-kernel clock;
+// the same binary on all-zero activations: 1.64 PFLOP/s).
+#define CONV256_MAX_BIAS 2048
+// m / d for 0 <= m < 2^31 and a quotient below 2^21 (image or row index): float estimate, +-1 fix-up.
+// Eight VALU instructions instead of the ~30 of the generic 32-bit division sequence.
+__device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
+    const int q = (int)((float)m * rcp_d);
+    const int r = m - q * d;
+    return q + (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+}
+#define SEG_SYNC_N(VM)                                                                      \
+    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define MMA_N(i, j, wfrag, FIRST, TAILBAR)                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                        \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                       \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p)                                   \
+                acc[i][j][c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[c][kk], xf[p][kk], \
+                    (FIRST && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j][c][p], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (TAILBAR) __builtin_amdgcn_s_barrier();                                              \
+    __builtin_amdgcn_sched_barrier(0);
+#define STEP_N(VM, FIRST, LAST)                                                             \
+    {                                                                                       \
+        const f16* buf = lds + sp * BUF_ELEMS;                                              \
+        LOAD_X(buf + SLOT_XA * HALF_ELEMS)                                                  \
+        LOAD_W(wa, buf + SLOT_WA * HALF_ELEMS)                                              \
+        stage(SLOT_WB, t + 1, sp ^ 1);                                                      \
+        SEG_SYNC_N(VM)                                                                      \
+        MMA_N(0, 0, wa, FIRST, 1)                                                           \
+        LOAD_W(wb, buf + SLOT_WB * HALF_ELEMS)                                              \
+        stage(SLOT_XB, t + 1, sp ^ 1);                                                      \
+        SEG_SYNC_N(VM)                                                                      \
+        MMA_N(0, 1, wb, FIRST, 1)                                                           \
+        LOAD_X(buf + SLOT_XB * HALF_ELEMS)                                                  \
+        stage(SLOT_XA, t + 2, sp);                                                          \
+        SEG_SYNC_N(VM)                                                                      \
+        MMA_N(1, 1, wb, FIRST, 1)                                                           \
+        stage(SLOT_WA, t + 2, sp);                                                          \
+        SEG_SYNC_N(VM)                                                                      \
+        MMA_N(1, 0, wa, FIRST, !(LAST))                                                     \
+        sp ^= 1;                                                                            \
+    }
+
+__global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias) {
+    __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
+    __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wc = wave >> 1;
+    const int T = a.ksteps;
+    // the op's whole bias vector lives in LDS and is read with ds_read in the epilogue, so that no
+    // vector-memory load sits between the DMA stream and the stores
+    for (int i = tid; i < nbias; i += 512) lds_bias[i] = a.bias[i];
+    __syncthreads();
+
+    // tile list of this workgroup: same XCD-contiguous order the one-tile kernel gets from the
+    // dispatcher, position v -> (group, pixel tile, channel tile)
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int chunk = (a.MT + 7) >> 3;
+    int mt_here = a.MT - xcd * chunk;
+    mt_here = mt_here < 0 ? 0 : (mt_here > chunk ? chunk : mt_here);
+    const int jbs = mt_here * a.NT;
+    const int vtotal = jbs * groups;
+    int v = blockIdx.x >> 3;
+    if (v >= vtotal) return;
+
+    const int rr = tid >> 3, cs = tid & 7;
+    const float rcp_hw = 1.0f / (float)a.HmWm, rcp_w = 1.0f / (float)a.Wm;
+    uint32_t xo_c[2][2], xo_n[2][2];        // DMA source offsets of the current / next tile
+    const f16 *wb_c, *wb_n;
+    int gi_c, gi_n, mt_c, mt_n, nt_c, nt_n;
+    auto locate = [&](int vv, uint32_t (&xo)[2][2], const f16*& wb, int& gi, int& mt, int& nt) {
+        gi = vv / jbs;
+        const int jb = vv - gi * jbs;
+        const int q = jb / a.NT;
+        nt = jb - q * a.NT;
+        mt = xcd * chunk + q;
+        const ConvGroupArgs& g = a.g[gi];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int m = mt * 256 + h * 128 + i * 64 + rr;
+                m = m < a.M ? m : a.M - 1;
+                const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
+                const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
+                const uint32_t pix = (uint32_t)((n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P);
+                xo[h][i] = pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8);
+            }
+        wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
+    };
+    bool live_n;
+    locate(v, xo_c, wb_c, gi_c, mt_c, nt_c);
+    // until the real successor is located (after the first K-tile) "n" aliases "c"
+    xo_n[0][0] = xo_c[0][0]; xo_n[0][1] = xo_c[0][1]; xo_n[1][0] = xo_c[1][0]; xo_n[1][1] = xo_c[1][1];
+    wb_n = wb_c; gi_n = gi_c; mt_n = mt_c; nt_n = nt_c; live_n = false;
+
+    f16* const dummy = lds + 2 * BUF_ELEMS;
+    // stage half-tile `slot` of the K-tile kpos steps into the current tile (kpos >= T: next tile;
+    // no next tile: same addresses into the dummy slot so the DMA count per phase stays constant)
+    auto stage = [&](int slot, int kpos, int par) {
+        const bool in_cur = kpos < T;
+        const int k = in_cur ? kpos : kpos - T;
+        f16* dst = (in_cur || live_n) ? (lds + par * BUF_ELEMS + slot * HALF_ELEMS) : dummy;
+        if (slot < 2) {
+            const int tap = k / a.cpt, q = k - tap * a.cpt;
+            const int koff = a.g[in_cur ? gi_c : gi_n].tap_off[tap] + q * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
+                const f16* src = a.in + (size_t)xo + (ptrdiff_t)koff;
+                __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)(dst + (i * 512 + wave * 64) * 8), 16, 0, 0);
+            }
+        } else {
+            const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ws + (i * 512 + tid) * 8),
+                                                 (LDS_AS void*)(dst + (i * 512 + wave * 64) * 8), 16, 0, 0);
         }
+    };
+
+    f32x4 acc[2][2][2][4];
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw0 = ((0 * 4 + fk) ^ (frow & 7)) * 8, sw1 = ((1 * 4 + fk) ^ (frow & 7)) * 8;
+    const int xrow = (wp * 64 + frow) * 64;
+    const int wrow = (wc * 32 + frow) * 64;
+    // after the permlane swap a lane stores channels [so, so+8) of its wave's 32-channel run
+    const int so = (fk & 1) * 16 + (fk >> 1) * 8;
+    const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
+    const f16x4 lo4 = {lo, lo, lo, lo};
+
+    // ---- prologue (once per workgroup): tile 0 complete, XA(1), WA(1) in flight
+    stage(SLOT_XA, 0, 0); stage(SLOT_WA, 0, 0); stage(SLOT_WB, 0, 0); stage(SLOT_XB, 0, 0);
+    stage(SLOT_XA, 1, 1); stage(SLOT_WA, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
+
+    f16x8 xf[4][2], wa[2][2], wb[2][2];
+    int sp = 0;                                           // LDS buffer of the current K-tile
+    for (;;) {
+        int t = 0;
+        STEP_N(24, 1, 0)
+        // successor tile: its first half-tiles are staged from K-tile T-2 of this one
+        live_n = v + per_xcd < vtotal;
+        if (live_n) locate(v + per_xcd, xo_n, wb_n, gi_n, mt_n, nt_n);
+        for (t = 1; t < T - 1; ++t) STEP_N(8, 0, 0)
+        STEP_N(8, 0, 1)
+        // The last MFMA segment has no trailing barrier.  Waves 0-3 take it here, before their
+        // epilogue, waves 4-7 (one barrier behind) after theirs: otherwise each group would sit at a
+        // barrier for the whole of the other group's epilogue (measured: 2 x 2.8 us per tile).
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+
+        // ---- epilogue of the current tile: no loads, 16 independent 16-byte stores
+        {
+            const ConvGroupArgs& g = a.g[gi_c];
+            const int cbase = g.out_coff + nt_c * 256 + wc * 32 + so;
+            f32x4 bv[2][2];
+            {
+                const float* bp = lds_bias + g.bias_off + nt_c * 256 + wc * 32 + fk * 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) bv[j][c] = *(const f32x4*)(bp + j * 128 + c * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                size_t opix[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    // rows past M were staged from pixel M-1 and hold its result: a same-value write
+                    int m = mt_c * 256 + i * 128 + wp * 64 + p * 16 + frow;
+                    m = m < a.M ? m : a.M - 1;
+                    const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
+                    const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
+                    const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+                    opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + cbase;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint32_t u[2][2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const f32x4 vv = acc[i][j][c][p] + bv[j][c];       // same order as the other conv kernels
+                            f16x4 h = {(f16)vv[0], (f16)vv[1], (f16)vv[2], (f16)vv[3]};
+                            h = __builtin_elementwise_max(h, lo4);       // ReLU (or -inf) on packed halves
+                            __builtin_memcpy(u[c], &h, 8);
+                        }
+                        // rows (16-lane groups) 1,3 of the c=0 registers <-> rows 0,2 of the c=1 registers
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        *(u32x4*)((f16*)a.out + opix[p] + j * 128) = o;
+                    }
+            }
+        }
+        if (wave >= 4) __builtin_amdgcn_s_barrier();
+        if (!live_n) break;
+        v += per_xcd;
+        xo_c[0][0] = xo_n[0][0]; xo_c[0][1] = xo_n[0][1]; xo_c[1][0] = xo_n[1][0]; xo_c[1][1] = xo_n[1][1];
+        wb_c = wb_n; gi_c = gi_n; mt_c = mt_n; nt_c = nt_n;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
+}
+
+static int device_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount;
+    }
+    return n;
 }
 
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, hipStream_t s) {
+    dim3 block(512, 1, 1);
+    int nbias = 0;
+    for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
+    nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
+    if (!a.res && a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS) {
+        const int chunk = (a.MT + 7) / 8;
+        int per_xcd = device_cu_count() / 8;
+        if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+        dim3 grid(per_xcd * 8, 1, 1);
+        hipLaunchKernelGGL(conv_mfma256_persistent_kernel, grid, block, 0, s, a, groups, nbias);
+        return hipGetLastError();
+    }
     const int mt8 = (a.MT + 7) / 8 * 8;
-    dim3 grid(mt8 * a.NT, groups, 1), block(512, 1, 1);
-    hipLaunchKernelGGL((conv_mfma256_kernel<0>), grid, block, 0, s, a);
+    dim3 grid(mt8 * a.NT, groups, 1);
+    if (a.res) hipLaunchKernelGGL((conv_mfma256_kernel<1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_mfma256_kernel<0>), grid, block, 0, s, a);
     return hipGetLastError();
 }
