@@ -11,6 +11,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// m / d for 0 <= m < 2^31 and a quotient below 2^21 (image or row index): float estimate, +-1 fix-up.
+// Eight VALU instructions instead of the ~30 of the generic 32-bit division sequence.
+__device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
+    const int q = (int)((float)m * rcp_d);
+    const int r = m - q * d;
+    return q + (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+}
+
+
 #define RT_MAX_GROUPS 4
 #define RT_MAX_TAPS 49
 

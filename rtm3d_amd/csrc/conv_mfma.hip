@@ -19,7 +19,7 @@
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
 
-template <int BM, int BN, int WGM, int WGN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int EPI, int RES>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     constexpr int XP = BM * 8;                 // 16-byte pieces of the pixel tile per k-step
     constexpr int WP = BN * 8;                 // pieces of the weight tile
@@ -48,12 +48,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     uint32_t xoff[XI];
     {
         const int rr = tid >> 3, cs = tid & 7;
+        const float rcp_hw0 = 1.0f / (float)a.HmWm, rcp_w0 = 1.0f / (float)a.Wm;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             int m = mtile * BM + i * 32 + rr;
             m = m < a.M ? m : a.M - 1;
-            const int n = m / a.HmWm, rem = m - n * a.HmWm;
-            const int y = rem / a.Wm, x = rem - y * a.Wm;
+            const int n = div_small_q(m, a.HmWm, rcp_hw0), rem = m - n * a.HmWm;
+            const int y = div_small_q(rem, a.Wm, rcp_w0), x = rem - y * a.Wm;
             const uint32_t pix = (uint32_t)((n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P);
             xoff[i] = pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8);
         }
@@ -114,34 +115,81 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
+    // Loads (bias, residual) first, then one run of independent stores: a load between two stores makes
+    // the compiler wait vmcnt(0), i.e. for the previous store's acknowledgement too.
+    const float rcp_hw = 1.0f / (float)a.HmWm, rcp_w = 1.0f / (float)a.Wm;
+    if (EPI == 0) {
+        constexpr bool WIDE = (TC % 2) == 0;       // pair two 16-channel tiles -> 16-byte stores
+        const int cw = ntile * BN + wc * (BN / WGN);
+        f32x4 bv[TC];
 #pragma unroll
-    for (int p = 0; p < TP; ++p) {
-        const int m = mtile * BM + wp * (BM / WGM) + p * 16 + frow;
-        if (m >= a.M) continue;
-        const int n = m / a.HmWm, rem = m - n * a.HmWm;
-        const int y = rem / a.Wm, x = rem - y * a.Wm;
-        const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+        for (int c = 0; c < TC; ++c) bv[c] = *(const f32x4*)(a.bias + g.bias_off + cw + c * 16 + fk * 4);
+        const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
+        const f16x4 lo4 = {lo, lo, lo, lo};
+        size_t opix[TP];
+        f16x4 rv[TP][TC];
 #pragma unroll
-        for (int c = 0; c < TC; ++c) {
-            const int c0 = ntile * BN + wc * (BN / WGN) + c * 16 + fk * 4;
-            if (c0 >= a.cout) continue;
-            f32x4 v = acc[c][p];
-            const float* bp = a.bias + g.bias_off + c0;
-            if (EPI == 0) {
-                const f32x4 b = *(const f32x4*)bp;
-                v += b;
-                if (a.res) {
-                    const size_t ro = ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff + c0;
-                    const f16x4 r = *(const f16x4*)(a.res + ro);
+        for (int p = 0; p < TP; ++p) {
+            // rows past M were staged from pixel M-1 and hold its result: a same-value write
+            int m = mtile * BM + wp * (BM / WGM) + p * 16 + frow;
+            m = m < a.M ? m : a.M - 1;
+            const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
+            const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
+            const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+            opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + cw;
+            if (RES) {
+                const f16* rp = a.res + ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff + cw + fk * 4;
+#pragma unroll
+                for (int c = 0; c < TC; ++c) rv[p][c] = *(const f16x4*)(rp + c * 16);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            f16x4 h[TC];
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                f32x4 v = acc[c][p] + bv[c];
+                if (RES) {
+                    const f16x4 r = rv[p][c];
                     v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
                 }
-                if (a.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                const f16x4 t = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                h[c] = __builtin_elementwise_max(t, lo4);
+            }
+            if (WIDE) {
+                // v_permlane16_swap: rows (16-lane groups) 1,3 of the even tile's registers <-> rows 0,2 of
+                // the odd tile's, after which a lane owns 8 consecutive channels of the 32-channel pair
+                const int so = (fk & 1) * 16 + (fk >> 1) * 8;
+#pragma unroll
+                for (int c = 0; c < TC; c += 2) {
+                    uint32_t u0[2], u1[2];
+                    __builtin_memcpy(u0, &h[c], 8);
+                    __builtin_memcpy(u1, &h[c + 1 < TC ? c + 1 : c], 8);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    if (cw + c * 16 + so < a.cout) *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;
                 }
-                const size_t oo = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + c0;
-                f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *(f16x4*)((f16*)a.out + oo) = h;
             } else {
+#pragma unroll
+                for (int c = 0; c < TC; ++c)
+                    if (cw + c * 16 + fk * 4 < a.cout) *(f16x4*)((f16*)a.out + opix[p] + c * 16 + fk * 4) = h[c];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            const int m = mtile * BM + wp * (BM / WGM) + p * 16 + frow;
+            if (m >= a.M) continue;
+            const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
+            const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
+            const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                const int c0 = ntile * BN + wc * (BN / WGN) + c * 16 + fk * 4;
+                if (c0 >= a.cout) continue;
+                const f32x4 v = acc[c][p];
+                const float* bp = a.bias + g.bias_off + c0;
                 float* o = (float*)a.out;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -162,9 +210,11 @@ static hipError_t launch_t(const ConvKArgs& a, int groups, int epi, hipStream_t 
     const int mt8 = (a.MT + 7) / 8 * 8;
     dim3 grid(mt8 * a.NT, groups, 1), block(256, 1, 1);
     if (epi)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, 1>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, 1, 0>), grid, block, 0, s, a);
+    else if (a.res)
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, 0, 1>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, 0>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WGM, WGN, 0, 0>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -234,13 +234,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // non-zero data they run at the rate the chip's power management allows (1.9 GHz in-kernel clock;
 // the same binary on all-zero activations: 1.64 PFLOP/s).
 #define CONV256_MAX_BIAS 2048
-// m / d for 0 <= m < 2^31 and a quotient below 2^21 (image or row index): float estimate, +-1 fix-up.
-// Eight VALU instructions instead of the ~30 of the generic 32-bit division sequence.
-__device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
-    const int q = (int)((float)m * rcp_d);
-    const int r = m - q * d;
-    return q + (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
-}
 #define SEG_SYNC_N(VM)                                                                      \
     asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
     __builtin_amdgcn_sched_barrier(0);                                                      \
