@@ -42,17 +42,24 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const ConvKArgs a) {
         else { const int kx = 2 * fk < 6 ? 2 * fk : 6; koff[s] = g.tap_off[s * 7 + kx]; }
     }
     const int ntiles = (a.M + 15) / 16;
-#pragma unroll 1
-    for (int it = 0; it < TPW; ++it) {
-        const int tile = wave * TPW + it;
-        if (tile >= ntiles) break;
+    const float rcp_hw = 1.0f / (float)a.HmWm, rcp_w = 1.0f / (float)a.Wm;
+    f32x4 bv[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) bv[c] = *(const f32x4*)(a.bias + g.bias_off + (ct0 + c) * 16 + fk * 4);
+    const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
+    const f16x4 lo4 = {lo, lo, lo, lo};
+
+    // pixel tile -> operand loads (rows past M re-read pixel M-1 and are not stored)
+    auto locate = [&](int tile, int& n, int& y, int& x) {
         int m = tile * 16 + frow;
-        const bool valid = m < a.M;
-        m = valid ? m : a.M - 1;
-        const int n = m / a.HmWm, rem = m - n * a.HmWm;
-        const int y = rem / a.Wm, x = rem - y * a.Wm;
+        m = m < a.M ? m : a.M - 1;
+        n = div_small_q(m, a.HmWm, rcp_hw);
+        const int rem = m - n * a.HmWm;
+        y = div_small_q(rem, a.Wm, rcp_w);
+        x = rem - y * a.Wm;
+    };
+    auto fetch = [&](int n, int y, int x, f16x8 (&xf)[S]) {
         const f16* ip = a.in + ((size_t)(n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P) * a.in_C + g.in_coff;
-        f16x8 xf[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (CIN == 4) {
@@ -62,6 +69,25 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const ConvKArgs a) {
                 xf[s] = *(const f16x8*)(ip + koff[s]);
             }
         }
+    };
+
+    // software pipeline: the operands of tile it+1 are in flight while tile it is multiplied and stored
+    const int tile0 = wave * TPW;
+    if (tile0 >= ntiles) return;
+    int n, y, x;
+    f16x8 xf[S];
+    locate(tile0, n, y, x);
+    fetch(n, y, x, xf);
+#pragma unroll 1
+    for (int it = 0; it < TPW; ++it) {
+        const int tile = tile0 + it;
+        const bool more = it + 1 < TPW && tile + 1 < ntiles;
+        int nn = n, ny = y, nx = x;
+        f16x8 xn[S];
+        if (more) {
+            locate(tile + 1, nn, ny, nx);
+            fetch(nn, ny, nx, xn);
+        }
         f32x4 acc[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -69,21 +95,38 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const ConvKArgs a) {
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][s], xf[s], acc[c], 0, 0, 0);
-        if (valid) {
-            const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
-            f16* op = (f16*)a.out + ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff;
+        f16x4 h[NCT];
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const int c0 = (ct0 + c) * 16 + fk * 4;
-                const f32x4 b = *(const f32x4*)(a.bias + g.bias_off + c0);
-                f32x4 v = acc[c] + b;
-                if (a.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                }
-                f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *(f16x4*)(op + c0) = h;
-            }
+        for (int c = 0; c < NCT; ++c) {
+            const f32x4 v = acc[c] + bv[c];
+            const f16x4 t = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            h[c] = __builtin_elementwise_max(t, lo4);
         }
+        const bool valid = tile * 16 + frow < a.M;
+        const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
+        f16* op = (f16*)a.out + ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + ct0 * 16;
+        if (NCT % 2 == 0) {
+            // v_permlane16_swap pairs two 16-channel tiles: a lane then owns 8 consecutive channels (16-byte store)
+            const int so = (fk & 1) * 16 + (fk >> 1) * 8;
+#pragma unroll
+            for (int c = 0; c < NCT; c += 2) {
+                uint32_t u0[2], u1[2];
+                __builtin_memcpy(u0, &h[c], 8);
+                __builtin_memcpy(u1, &h[c + 1 < NCT ? c + 1 : c], 8);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                if (valid) *(u32x4*)(op + c * 16 + so) = o;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                if (valid) *(f16x4*)(op + c * 16 + fk * 4) = h[c];
+        }
+        if (!more) break;
+        n = nn; y = ny; x = nx;
+#pragma unroll
+        for (int s = 0; s < S; ++s) xf[s] = xn[s];
     }
 }
 
@@ -92,8 +135,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
                                                             int Hp, int Wp, int P) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * H * W) return;
-    const int n = idx / (H * W), rem = idx - n * (H * W);
-    const int y = rem / W, x = rem - y * W;
+    const int n = div_small_q(idx, H * W, 1.0f / (float)(H * W)), rem = idx - n * (H * W);
+    const int y = div_small_q(rem, W, 1.0f / (float)W), x = rem - y * W;
     const size_t plane = (size_t)H * W;
     const float* p = in + (size_t)n * 3 * plane + (size_t)y * W + x;
     f16x4 v = {(f16)p[0], (f16)p[plane], (f16)p[2 * plane], (f16)0.f};
