@@ -19,7 +19,7 @@
 #define HO_STAGE (HO_PIX * 64)            // halves per chunk stage
 
 __global__ __launch_bounds__(256) void conv_headout_kernel(const HeadOutArgs a) {
-    // single 44 KB stage: three workgroups per CU overlap each other's DMA / MFMA phases
+    // single 44 KB stage: two to three workgroups per CU overlap each other's DMA / MFMA phases
     __shared__ __attribute__((aligned(16))) f16 lds[HO_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,9 +60,17 @@ __global__ __launch_bounds__(256) void conv_headout_kernel(const HeadOutArgs a) 
     for (int p = 0; p < 4; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f16* wp = a.wgt + (size_t)head * 9 * 8 * 64 * 8 + lane * 8;
 
+    const f32x4 bias4 = *(const f32x4*)(a.bias + head * 16 + fk * 4);
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         stage(0, c);
+        // the chunk's 18 weight fragments (9 taps x 2 k-halves) are fetched beside the halo DMA: one wait
+        // for both at the barrier instead of a vmcnt(0) round trip in front of every MFMA group
+        f16x8 wfr[18];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wfr[tap * 2 + kk] = *(const f16x8*)(wp + (size_t)(tap * 8 + c * 2 + kk) * 64 * 8);
         __syncthreads();
         const f16* xl = lds;
 #pragma unroll
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_headout_kernel(const HeadOutArgs a) 
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const f16x8 wf = *(const f16x8*)(wp + (size_t)(tap * 8 + c * 2 + kk) * 64 * 8);
+                const f16x8 wf = wfr[tap * 2 + kk];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int q = (2 * wave + (p >> 1) + 1 + dy) * HO_HW + (p & 1) * 16 + frow + 1 + dx;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_headout_kernel(const HeadOutArgs a) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int cc = fk * 4 + e;
-            if (cc < co) o[((size_t)(n * co + cc) * a.H + y) * a.W + x] = acc[p][e] + a.bias[head * 16 + cc];
+            if (cc < co) o[((size_t)(n * co + cc) * a.H + y) * a.W + x] = acc[p][e] + bias4[e];
         }
     }
 }
