@@ -37,38 +37,50 @@ hipError_t launch_maxpool(const PoolKArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------- spatial softmax fusion
 // pass 1: per (u, image, row-chunk) partial (max, sum exp) for each of the 256 channels.
+// A lane owns 8 channels (16-byte loads), a wave instruction covers two pixels, four pixels are in
+// flight per lane; the running sum is rescaled once per batch of four values, not per value.
 __global__ __launch_bounds__(256) void softmax_reduce_kernel(const SoftmaxKArgs a) {
     const int chunk = blockIdx.x, n = blockIdx.y, ui = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 31, slot = wave * 2 + (lane >> 5);        // 8 pixel slots per workgroup
     const f16* u = a.u[ui];
     const int Hp = a.u_Hp[ui], Wp = a.u_Wp[ui], C = a.u_C[ui], P = a.u_P[ui];
-    float m[4], s[4];
+    float m[8], s[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { m[e] = -INFINITY; s[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; s[e] = 0.f; }
     const int y0 = chunk * a.rows_per_chunk;
     const int y1 = min(y0 + a.rows_per_chunk, a.H);
     for (int y = y0; y < y1; ++y) {
-        const f16* row = u + ((size_t)(n * Hp + y + P) * Wp + P) * C + lane * 4;
-        for (int x = wave; x < a.W; x += 4) {
-            const f16x4 v = *(const f16x4*)(row + (size_t)x * C);
+        const f16* row = u + ((size_t)(n * Hp + y + P) * Wp + P) * C + cg * 8;
+        for (int x = slot; x < a.W; x += 32) {
+            f16x8 v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float f = (float)v[e];
-                const float mn = fmaxf(m[e], f);
-                s[e] = s[e] * __expf(m[e] - mn) + __expf(f - mn);
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x + 8 * k < a.W ? x + 8 * k : x;          // tail: re-read a pixel already counted ...
+                v[k] = *(const f16x8*)(row + (size_t)xx * C);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = (x + 8 * k < a.W) ? (float)v[k][e] : -INFINITY;   // ... with weight exp(-inf) = 0
+                const float mn = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), m[e]);
+                s[e] = s[e] * __expf(m[e] - mn) + ((__expf(f[0] - mn) + __expf(f[1] - mn)) + (__expf(f[2] - mn) + __expf(f[3] - mn)));
                 m[e] = mn;
             }
         }
     }
-    __shared__ float sm[4][256], ss[4][256];
+    __shared__ float sm[8][256], ss[8][256];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sm[wave][lane * 4 + e] = m[e]; ss[wave][lane * 4 + e] = s[e]; }
+    for (int e = 0; e < 8; ++e) { sm[slot][cg * 8 + e] = m[e]; ss[slot][cg * 8 + e] = s[e]; }
     __syncthreads();
     const int c = threadIdx.x;   // 256 threads <-> 256 channels
-    float M = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) M = fmaxf(M, sm[w][c]);
     float S = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) S += (sm[w][c] == -INFINITY) ? 0.f : ss[w][c] * __expf(sm[w][c] - M);
+    for (int w = 0; w < 8; ++w) S += (sm[w][c] == -INFINITY) ? 0.f : ss[w][c] * __expf(sm[w][c] - M);
     float* out = a.partial + ((((size_t)ui * a.B + n) * a.chunks + chunk) * a.C + c) * 2;
     out[0] = M; out[1] = S;
 }
@@ -88,34 +100,52 @@ __global__ __launch_bounds__(256) void softmax_combine_kernel(const SoftmaxKArgs
     o[0] = mm; o[1] = 1.f / ssum;
 }
 
-// pass 3: z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i
+// pass 3: z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i      (16-byte lanes, two pixels in flight per lane)
+template <int NU>
 __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a) {
     const int chunk = blockIdx.x, n = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float M[3][4], invS[3][4];
-    for (int ui = 0; ui < a.n_u; ++ui) {
-        const float* st = a.stats + (((size_t)ui * a.B + n) * a.C + lane * 4) * 2;
+    const int cg = lane & 31, slot = wave * 2 + (lane >> 5);
+    float M[NU][8], invS[NU][8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { M[ui][e] = st[2 * e]; invS[ui][e] = st[2 * e + 1]; }
+    for (int ui = 0; ui < NU; ++ui) {
+        const float* st = a.stats + (((size_t)ui * a.B + n) * a.C + cg * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { M[ui][e] = st[2 * e]; invS[ui][e] = st[2 * e + 1]; }
     }
     const int y0 = chunk * a.rows_per_chunk;
     const int y1 = min(y0 + a.rows_per_chunk, a.H);
     for (int y = y0; y < y1; ++y) {
-        const size_t zrow = ((size_t)(n * a.z_Hp + y + a.z_P) * a.z_Wp + a.z_P) * a.z_C + lane * 4;
-        const size_t zirow = ((size_t)(n * a.zi_Hp + y + a.zi_P) * a.zi_Wp + a.zi_P) * a.zi_C + lane * 4;
-        for (int x = wave; x < a.W; x += 4) {
-            const f16x4 zi = *(const f16x4*)(a.z_in + zirow + (size_t)x * a.zi_C);
-            float acc[4] = {(float)zi[0], (float)zi[1], (float)zi[2], (float)zi[3]};
-            for (int ui = 0; ui < a.n_u; ++ui) {
-                const f16x4 v = *(const f16x4*)(a.u[ui] + ((size_t)(n * a.u_Hp[ui] + y + a.u_P[ui]) * a.u_Wp[ui] + a.u_P[ui] + x) * a.u_C[ui] + lane * 4);
+        const size_t zrow = ((size_t)(n * a.z_Hp + y + a.z_P) * a.z_Wp + a.z_P) * a.z_C + cg * 8;
+        const size_t zirow = ((size_t)(n * a.zi_Hp + y + a.zi_P) * a.zi_Wp + a.zi_P) * a.zi_C + cg * 8;
+        size_t urow[NU];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float f = (float)v[e];
-                    acc[e] += f * (__expf(f - M[ui][e]) * invS[ui][e]);
-                }
+        for (int ui = 0; ui < NU; ++ui) urow[ui] = ((size_t)(n * a.u_Hp[ui] + y + a.u_P[ui]) * a.u_Wp[ui] + a.u_P[ui]) * a.u_C[ui] + cg * 8;
+        for (int x = slot; x < a.W; x += 16) {
+            f16x8 zi[2], v[2][NU];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int xx = x + 8 * k < a.W ? x + 8 * k : x;
+                zi[k] = *(const f16x8*)(a.z_in + zirow + (size_t)xx * a.zi_C);
+#pragma unroll
+                for (int ui = 0; ui < NU; ++ui) v[k][ui] = *(const f16x8*)(a.u[ui] + urow[ui] + (size_t)xx * a.u_C[ui]);
             }
-            f16x4 o = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-            *(f16x4*)(a.z_out + zrow + (size_t)x * a.z_C) = o;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (x + 8 * k >= a.W) break;
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float acc = (float)zi[k][e];
+#pragma unroll
+                    for (int ui = 0; ui < NU; ++ui) {
+                        const float f = (float)v[k][ui][e];
+                        acc += f * (__expf(f - M[ui][e]) * invS[ui][e]);
+                    }
+                    o[e] = (f16)acc;
+                }
+                *(f16x8*)(a.z_out + zrow + (size_t)(x + 8 * k) * a.z_C) = o;
+            }
         }
     }
 }
@@ -124,6 +154,8 @@ hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s) {
     if (a.C != 256 || a.n_u < 1 || a.n_u > 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(softmax_reduce_kernel, dim3(a.chunks, a.B, a.n_u), dim3(256), 0, s, a);
     hipLaunchKernelGGL(softmax_combine_kernel, dim3(a.B, a.n_u, 1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(softmax_apply_kernel, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
+    if (a.n_u == 3) hipLaunchKernelGGL(softmax_apply_kernel<3>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
+    else if (a.n_u == 2) hipLaunchKernelGGL(softmax_apply_kernel<2>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(softmax_apply_kernel<1>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
