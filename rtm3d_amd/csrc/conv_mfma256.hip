@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Persistent form (default when there is no residual operand and the K loop has >= 4 tiles).
-// One workgroup per CU walks its XCD's list of output tiles:
+// One workgroup per CU draws output tiles from its XCD's list (ticket counter):
 //   * the half-tile DMA pipeline runs straight across tile boundaries: the last two K-tiles of a
 //     tile already stage the first two of the next one (descriptor "n"), so there is no prologue,
 //     no drain and no workgroup launch between tiles;
@@ -234,8 +234,23 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // non-zero data they run at the rate the chip's power management allows (1.9 GHz in-kernel clock;
 // the same binary on all-zero activations: 1.64 PFLOP/s).
 #define CONV256_MAX_BIAS 2048
+// Operand reads as inline asm: the compiler's waitcnt pass treats a ds_read it can see as possibly
+// aliasing every pending global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which would drain
+// the DMA pipeline in every phase; ordering against the DMA is what SEG_SYNC_N's counted vmcnt is for.
+// The reads' own completion is the lgkmcnt(0) in SEG_SYNC_N.
+#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define LOAD_X_N(SLOT)                                                                      \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
+        DS_READ_B128(xf[p][0], xaddr0, (SLOT) * HALF_ELEMS * 2 + p * 2048);                 \
+        DS_READ_B128(xf[p][1], xaddr1, (SLOT) * HALF_ELEMS * 2 + p * 2048);                 \
+    }
+#define LOAD_W_N(dstf, SLOT)                                                                \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                         \
+        DS_READ_B128(dstf[c][0], waddr0, (SLOT) * HALF_ELEMS * 2 + c * 2048);               \
+        DS_READ_B128(dstf[c][1], waddr1, (SLOT) * HALF_ELEMS * 2 + c * 2048);               \
+    }
 #define SEG_SYNC_N(VM)                                                                      \
-    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                       \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     __builtin_amdgcn_s_barrier();                                                           \
     __builtin_amdgcn_sched_barrier(0);
@@ -252,17 +267,19 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #define STEP_N(VM, FIRST, LAST)                                                             \
     {                                                                                       \
-        const f16* buf = lds + sp * BUF_ELEMS;                                              \
-        LOAD_X(buf + SLOT_XA * HALF_ELEMS)                                                  \
-        LOAD_W(wa, buf + SLOT_WA * HALF_ELEMS)                                              \
+        const uint32_t bufb = lds_base + (uint32_t)sp * (BUF_ELEMS * 2);                    \
+        const uint32_t xaddr0 = bufb + xrow_b0, xaddr1 = bufb + xrow_b1;                    \
+        const uint32_t waddr0 = bufb + wrow_b0, waddr1 = bufb + wrow_b1;                    \
+        LOAD_X_N(SLOT_XA)                                                                   \
+        LOAD_W_N(wa, SLOT_WA)                                                               \
         stage(SLOT_WB, t + 1, sp ^ 1);                                                      \
         SEG_SYNC_N(VM)                                                                      \
         MMA_N(0, 0, wa, FIRST, 1)                                                           \
-        LOAD_W(wb, buf + SLOT_WB * HALF_ELEMS)                                              \
+        LOAD_W_N(wb, SLOT_WB)                                                               \
         stage(SLOT_XB, t + 1, sp ^ 1);                                                      \
         SEG_SYNC_N(VM)                                                                      \
         MMA_N(0, 1, wb, FIRST, 1)                                                           \
-        LOAD_X(buf + SLOT_XB * HALF_ELEMS)                                                  \
+        LOAD_X_N(SLOT_XB)                                                                   \
         stage(SLOT_XA, t + 2, sp);                                                          \
         SEG_SYNC_N(VM)                                                                      \
         MMA_N(1, 1, wb, FIRST, 1)                                                           \
@@ -272,9 +289,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         sp ^= 1;                                                                            \
     }
 
-__global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias) {
+__global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
-    __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS];
+    __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS + 4];   // + two ticket words
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,7 +310,24 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     mt_here = mt_here < 0 ? 0 : (mt_here > chunk ? chunk : mt_here);
     const int jbs = mt_here * a.NT;
     const int vtotal = jbs * groups;
-    int v = blockIdx.x >> 3;
+    // Tiles are handed out by a per-XCD ticket counter, so a workgroup that starts late (its CU was still
+    // held by another stream's waves) or runs slower simply takes fewer tiles.  Every workgroup draws
+    // tickets until it gets one >= vtotal, i.e. vtotal + per_xcd draws per XCD and launch; the last draw
+    // puts the counter back to zero for the next launch.
+    int* const lds_ticket = (int*)(lds_bias + CONV256_MAX_BIAS);
+    const int last_draw = vtotal + per_xcd - 1;
+    // Tickets are drawn two tiles ahead: slot (i & 1) of lds_ticket holds tile i's, and is refilled with
+    // tile i+2's while tile i runs.
+    if (tid == 0) {
+        const int t0 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        int t1 = t0;
+        if (t0 < vtotal) t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        if (t0 == last_draw || t1 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[0] = t0; lds_ticket[1] = t1;
+    }
+    __syncthreads();
+    const int v = __builtin_amdgcn_readfirstlane(lds_ticket[0]);
+    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (v >= vtotal) return;
 
     const int rr = tid >> 3, cs = tid & 7;
@@ -355,8 +389,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     f32x4 acc[2][2][2][4];
     const int frow = lane & 15, fk = lane >> 4;
     const int sw0 = ((0 * 4 + fk) ^ (frow & 7)) * 8, sw1 = ((1 * 4 + fk) ^ (frow & 7)) * 8;
-    const int xrow = (wp * 64 + frow) * 64;
-    const int wrow = (wc * 32 + frow) * 64;
+    // LDS byte addresses (within a K-tile buffer) of this lane's operand rows, k-halves 0 and 1
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
+    const uint32_t xrow_b0 = (uint32_t)(((wp * 64 + frow) * 64 + sw0) * 2), xrow_b1 = (uint32_t)(((wp * 64 + frow) * 64 + sw1) * 2);
+    const uint32_t wrow_b0 = (uint32_t)(((wc * 32 + frow) * 64 + sw0) * 2), wrow_b1 = (uint32_t)(((wc * 32 + frow) * 64 + sw1) * 2);
     // after the permlane swap a lane stores channels [so, so+8) of its wave's 32-channel run
     const int so = (fk & 1) * 16 + (fk >> 1) * 8;
     const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
@@ -371,12 +407,33 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 
     f16x8 xf[4][2], wa[2][2], wb[2][2];
     int sp = 0;                                           // LDS buffer of the current K-tile
+    int tpar = 0;
     for (;;) {
+        // draw the ticket of the tile after next (unless the last draw already came back empty); it is
+        // published through LDS after the first K-tile.  Inline asm: were this a returning VMEM op the
+        // compiler knows about, it would drain vmcnt(0) at the join; the explicit vmcnt(8) below - the
+        // atomic is older than the first K-tile's 8 DMA instructions - is the wait for its result.
+        int ticket = vnext;
+        const bool draw = vnext < vtotal;
+        if (wave == 0 && draw) {
+            // one lane only: 64 same-address atomics per draw serialise in L2 (measured: 3x slower kernels)
+            const unsigned inc = 1u, off = (unsigned)xcd * 4u;
+            unsigned long long saved_exec;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                         : "=&v"(ticket), "=&s"(saved_exec) : "v"(off), "v"(inc), "s"(tile_ctr) : "memory");
+        }
         int t = 0;
         STEP_N(24, 1, 0)
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(ticket) : : "memory");
+            if (lane == 0) {
+                lds_ticket[tpar] = ticket;
+                if (draw && ticket == last_draw) tile_ctr[xcd] = 0u;
+            }
+        }
         // successor tile: its first half-tiles are staged from K-tile T-2 of this one
-        live_n = v + per_xcd < vtotal;
-        if (live_n) locate(v + per_xcd, xo_n, wb_n, gi_n, mt_n, nt_n);
+        live_n = draw;
+        if (live_n) locate(vnext, xo_n, wb_n, gi_n, mt_n, nt_n);
         for (t = 1; t < T - 1; ++t) STEP_N(8, 0, 0)
         STEP_N(8, 0, 1)
         // The last MFMA segment has no trailing barrier.  Waves 0-3 take it here, before their
@@ -431,7 +488,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         }
         if (wave >= 4) __builtin_amdgcn_s_barrier();
         if (!live_n) break;
-        v += per_xcd;
+        vnext = __builtin_amdgcn_readfirstlane(lds_ticket[tpar]);
+        tpar ^= 1;
         xo_c[0][0] = xo_n[0][0]; xo_c[0][1] = xo_n[0][1]; xo_c[1][0] = xo_n[1][0]; xo_c[1][1] = xo_n[1][1];
         wb_c = wb_n; gi_c = gi_n; mt_c = mt_n; nt_c = nt_n;
     }
@@ -449,17 +507,17 @@ static int device_cu_count() {
     return n;
 }
 
-hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, hipStream_t s) {
+hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, hipStream_t s) {
     dim3 block(512, 1, 1);
     int nbias = 0;
     for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
     nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
-    if (!a.res && a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS) {
+    if (!a.res && a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
         const int chunk = (a.MT + 7) / 8;
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
         dim3 grid(per_xcd * 8, 1, 1);
-        hipLaunchKernelGGL(conv_mfma256_persistent_kernel, grid, block, 0, s, a, groups, nbias);
+        hipLaunchKernelGGL(conv_mfma256_persistent_kernel, grid, block, 0, s, a, groups, nbias, tile_ctr);
         return hipGetLastError();
     }
     const int mt8 = (a.MT + 7) / 8 * 8;

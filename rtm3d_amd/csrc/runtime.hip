@@ -47,6 +47,7 @@ struct rtm3d_ctx {
     std::vector<size_t> blob_bytes;
     std::vector<Op> ops;
     std::vector<void*> extra;   // other device allocations (softmax partials)
+    unsigned int* tile_ctr = nullptr;   // 8 per-XCD ticket counters of the persistent conv kernel (self-resetting)
     // live probe: hipEvent pairs around one op of every replay (bench.py roofline)
     int probe_op = -1;
     std::vector<hipEvent_t> probe_ev;   // 2 * PROBE_RING events
@@ -211,6 +212,11 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         if (bbytes != (size_t)d->cout * d->groups * sizeof(float)) RT_FAIL("op_conv(mfma256): bias blob size mismatch");
         for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = d->cout * g; }
         op.kind = OP_CONV_MFMA256; op.bn_tile = 256;
+        if (!ctx->tile_ctr) {
+            RT_HIP(hipMalloc((void**)&ctx->tile_ctr, 8 * sizeof(unsigned int)));
+            RT_HIP(hipMemset(ctx->tile_ctr, 0, 8 * sizeof(unsigned int)));
+            ctx->extra.push_back(ctx->tile_ctr);
+        }
         op.name = d->ntaps == 1 ? "conv1x1_mfma256" : (d->ntaps == 4 ? "deconv4x4_phase_mfma256" : "conv3x3_mfma256");
     } else if (d->kernel == 0) {
         const int BN = d->bn_tile;
@@ -343,7 +349,7 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
     return 0;
 }
 
-static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_out[4]) {
+static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, float* const d_out[4]) {
     hipError_t e = hipSuccess;
     switch (op.kind) {
         case OP_CONV_MFMA: {
@@ -352,7 +358,7 @@ static int launch_op(Op& op, hipStream_t s, const float* d_in, float* const d_ou
             e = launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
             break;
         }
-        case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, s); break;
+        case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
         case OP_HEADOUT: {
@@ -378,7 +384,7 @@ extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, fl
         const bool probe = (i == ctx->probe_op);
         const int slot = ctx->probe_count % PROBE_RING;
         if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], (hipStream_t)stream));
-        if (launch_op(ctx->ops[i], (hipStream_t)stream, d_in, d_out_logits)) return 1;
+        if (launch_op(ctx, ctx->ops[i], (hipStream_t)stream, d_in, d_out_logits)) return 1;
         if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], (hipStream_t)stream)); ctx->probe_count++; }
     }
     return 0;
@@ -422,7 +428,7 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     hipStream_t s = (hipStream_t)stream;
     RT_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < n; ++i) {
-        if (launch_op(ctx->ops[i], s, d_in, d_out_logits)) return 1;
+        if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) return 1;
         RT_HIP(hipEventRecord(ev[i + 1], s));
     }
     RT_HIP(hipEventSynchronize(ev[n]));
