@@ -41,7 +41,10 @@ CONV_CASES = [
     (1, 12, 20, 256, 64, 1, 1, 1, True, False, 0, 0),       # 1x1
     (1, 20, 36, 64, 256, 3, 1, 6, True, False, 0, 0),       # dilation 6 (head conv)
     (3, 24, 40, 64, 256, 3, 1, 1, True, True, 2, 0),        # mfma256, ragged M (2880 = 11.25 tiles), residual
-    (1, 16, 20, 128, 512, 3, 1, 6, False, False, 2, 0),     # mfma256, NT=2, single partial tile... M=320
+    (1, 16, 20, 128, 512, 3, 1, 6, False, False, 2, 0),     # mfma256 persistent, NT=2, M=320: six XCDs get no tile
+    (3, 24, 40, 64, 256, 3, 1, 1, True, False, 2, 0),       # mfma256 persistent, ragged M (11.25 tiles), 9 K-tiles
+    (2, 12, 20, 256, 256, 1, 1, 1, False, False, 2, 64),    # mfma256 persistent, 1x1: the minimum of 4 K-tiles
+    (4, 96, 160, 256, 256, 1, 1, 1, True, False, 2, 0),     # mfma256 persistent, 240 tiles: every workgroup draws several tickets
     (2, 16, 24, 16, 16, 3, 1, 1, True, False, 3, 0),        # smallc 16->16
     (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
     (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
@@ -79,6 +82,33 @@ def test_conv_kernels_vs_torch(case):
         ref = ref.relu()
     ref = h(ref).numpy()
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
+def test_persistent_conv_replays_identically():
+    """The persistent conv kernel hands out tiles through per-XCD ticket counters that the last draw of a
+    launch resets: ten replays of one context (and a second context in between) must all give the
+    first launch's bytes."""
+    rng = np.random.default_rng(7)
+    outs = []
+    for rep in range(2):
+        P = plan_mod.Plan(2, 96 * 4, 160 * 4)
+        xt = P.tensor(96, 160, 256, 1)
+        yt = P.tensor(96, 160, 256, 1)
+        P.conv(xt, yt, (np.random.default_rng(1).standard_normal((256, 256, 3, 3)) / 48).astype(np.float32), np.zeros(256, np.float32), relu=True, name='t')
+        P.ops[-1]['variant'] = 2
+        R = plan_mod.RealizedPlan(P, 0)
+        x = np.random.default_rng(2).standard_normal((2, 256, 96, 160)).astype(np.float32)
+        _lib.check(R.lib.rtm3d_tensor_upload(R.ctx, R.tids[xt.tid], 0, 256, x.ctypes.data_as(ctypes.c_void_p)))
+        xin = torch.zeros(16, device='cuda')
+        o = [torch.zeros(16, device='cuda') for _ in range(4)]
+        for it in range(10):
+            R.forward(torch.cuda.current_stream().cuda_stream, xin.data_ptr(), [t.data_ptr() for t in o])
+            torch.cuda.synchronize()
+            outs.append(R.download(yt))
+        R.close()
+    assert np.abs(outs[0]).max() > 0
+    for got in outs[1:]:
+        np.testing.assert_array_equal(got, outs[0])
 
 
 @pytest.mark.parametrize('shape', [(2, 6, 10, 0), (1, 12, 40, 0), (4, 24, 80, 2), (32, 12, 40, 2)])
