@@ -40,16 +40,22 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
     status[i] = st;
 }
 
-// One wavefront per object (lbfgsb_wave.h): the production kernel.  blockIdx.x = object / slot.
-__global__ __launch_bounds__(64, 4) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
+// One wavefront per object (lbfgsb_wave.h): the production kernel.  A workgroup packs D3_WPB objects
+// (8 waves, 90 KB of LDS): the ~15 objects of an image then sit on two CUs instead of fifteen, which
+// matters when this kernel runs beside the forward pass of the next batch - a CU that holds even one
+// of these waves cannot take a workgroup of the persistent conv kernel until the wave retires.
+#define D3_WPB 8
+__global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
                                                            const double* __restrict__ dim_ref, int ncls,
                                                            const double* __restrict__ ref_loc, double* __restrict__ x_out,
                                                            double* __restrict__ f_out, int32_t* __restrict__ nit,
                                                            int32_t* __restrict__ status,
                                                            const int32_t* __restrict__ n_per_image, int topk) {
-    __shared__ LbWaveMem mem;
-    const int i = blockIdx.x, lane = threadIdx.x;
+    __shared__ LbWaveMem mems[D3_WPB];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    LbWaveMem& mem = mems[wave];
+    const int i = blockIdx.x * D3_WPB + wave;
     if (i >= N) return;
     int ki = i;
     if (n_per_image) {
@@ -66,11 +72,11 @@ __global__ __launch_bounds__(64, 4) void decode3d_wave_kernel(int N, const int64
         mem.x[0] = 0.0; mem.x[1] = 1.0; mem.x[2] = dim[2]; mem.x[3] = dim[0]; mem.x[4] = dim[1];
         mem.x[5] = ref_loc[0]; mem.x[6] = ref_loc[1]; mem.x[7] = ref_loc[2];
     }
-    __syncthreads();
+    WSYNC();
     double f;
     int it;
     const int st = lbw_minimize(&mem, Kk, &f, &it, lane, 15000, 15000);
-    __syncthreads();
+    WSYNC();
     if (lane < 8) x_out[(size_t)i * 8 + lane] = mem.x[lane];
     if (lane == 0) { f_out[i] = f; nit[i] = it; status[i] = st; }
 }
@@ -85,7 +91,7 @@ extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const f
     if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
         rt_set_error("decode3d: null pointer"); return 1;
     }
-    hipLaunchKernelGGL(decode3d_wave_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+    hipLaunchKernelGGL(decode3d_wave_kernel, dim3((N + D3_WPB - 1) / D3_WPB), dim3(64 * D3_WPB), 0, (hipStream_t)stream, N, d_cls, d_verts,
                        d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d launch: %s", hipGetErrorString(e)); return 1; }
@@ -101,7 +107,7 @@ extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t
         rt_set_error("decode3d_slots: null pointer"); return 1;
     }
     const int N = B * topk;
-    hipLaunchKernelGGL(decode3d_wave_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+    hipLaunchKernelGGL(decode3d_wave_kernel, dim3((N + D3_WPB - 1) / D3_WPB), dim3(64 * D3_WPB), 0, (hipStream_t)stream, N, d_cls, d_verts,
                        d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d_slots launch: %s", hipGetErrorString(e)); return 1; }

@@ -10,14 +10,15 @@
 //     partial sums updated in pivot order (identical rounding to the dot-product form),
 //   - scalar control (line search state, convergence tests) is computed redundantly by every lane
 //     from LDS broadcasts, so control flow stays wave-uniform without any cross-lane traffic.
-// The workgroup is a single wave, so __syncthreads() is only an LDS ordering fence.
+// A wave's LDS instructions execute in order, so WSYNC() is only a compiler/LDS ordering fence at
+// wavefront scope (no s_barrier): a workgroup may hold several independent objects, one per wave.
 #pragma once
 #include "lbfgsb.h"
 
 #if defined(__HIPCC__)
 #pragma clang fp contract(off)
 
-#define WSYNC() __syncthreads()
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 struct LbWaveMem {
     double ws[LB_N * LB_M], wy[LB_N * LB_M];
