@@ -130,6 +130,110 @@ __global__ __launch_bounds__(256) void conv_smallc_kernel(const ConvKArgs a) {
     }
 }
 
+// Vertical walk (stride-1 layers): a wave owns a 16-pixel-wide column strip and walks down R output rows.
+// The K-steps are whole filter rows (CIN=4: one step per row; CIN=16: two steps per row, taps (ky,0),(ky,1)
+// and (ky,2),zero), so moving down one output row keeps KR-1 of the KR operand rows in registers: one
+// (CIN=16: two) 16-byte loads per lane and tile instead of 7 (5).  The loads of the next row are in flight
+// while the current tile is multiplied and stored.
+template <int CIN, int NCT, int KR, int SPR, int R>
+__global__ __launch_bounds__(256) void conv_smallc_rows_kernel(const ConvKArgs a, const int tiles_x, const int strips_y, const int nwaves) {
+    constexpr int S = KR * SPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int frow = lane & 15, fk = lane >> 4;
+    const ConvGroupArgs& g = a.g[0];
+    const int ct0 = blockIdx.y * NCT;
+    const int xb = wave % tiles_x, wq = wave / tiles_x;
+    const int sy = wq % strips_y, n = wq / strips_y;
+    const int H = a.HmWm / a.Wm, W = a.Wm;
+
+    f16x8 wf[NCT][S];
+    {
+        const f16* wp = a.wgt + g.w_off;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int s = 0; s < S; ++s) wf[c][s] = *(const f16x8*)(wp + ((size_t)((ct0 + c) * S + s) * 64 + lane) * 8);
+    }
+    // per-lane element offset of its 16-byte piece, per filter row and k-step of the row
+    int koff[KR][SPR];
+#pragma unroll
+    for (int ky = 0; ky < KR; ++ky) {
+        if (CIN == 4) {
+            const int kx = 2 * fk < 6 ? 2 * fk : 6;
+            koff[ky][0] = g.tap_off[ky * 7 + kx];
+        } else {
+            koff[ky][0] = g.tap_off[ky * 3 + (fk >> 1)] + (fk & 1) * 8;
+            koff[ky][SPR - 1] = g.tap_off[ky * 3 + 2] + (fk & 1) * 8;        // lane groups 2,3 carry zero weights there
+        }
+    }
+    f32x4 bv[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) bv[c] = *(const f32x4*)(a.bias + g.bias_off + (ct0 + c) * 16 + fk * 4);
+    const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
+    const f16x4 lo4 = {lo, lo, lo, lo};
+
+    const int y0 = sy * R, y1 = y0 + R < H ? y0 + R : H;
+    int x = xb * 16 + frow;
+    const bool xvalid = x < W;
+    x = xvalid ? x : W - 1;
+    const f16* ip = a.in + ((size_t)(n * a.in_Hp + y0 + a.in_P) * a.in_Wp + x + a.in_P) * a.in_C + g.in_coff;
+    const size_t in_pitch = (size_t)a.in_Wp * a.in_C;
+    f16* op = (f16*)a.out + ((size_t)(n * a.out_Hp + y0 * a.out_scale + g.out_oy + a.out_P) * a.out_Wp + x * a.out_scale + g.out_ox + a.out_P) * a.out_C
+              + g.out_coff + ct0 * 16;
+    const size_t out_pitch = (size_t)a.out_Wp * a.out_C * a.out_scale;
+
+    auto fetch = [&](const f16* p, f16x8& dst) {
+        if (CIN == 4) {
+            const f16x8_a8 t = *(const f16x8_a8*)p;
+            __builtin_memcpy(&dst, &t, 16);
+        } else {
+            dst = *(const f16x8*)p;
+        }
+    };
+    f16x8 xr[KR][SPR];
+#pragma unroll
+    for (int ky = 0; ky < KR; ++ky)
+#pragma unroll
+        for (int sp = 0; sp < SPR; ++sp) fetch(ip + koff[ky][sp], xr[ky][sp]);
+
+#pragma unroll 1
+    for (int y = y0; y < y1; ++y) {
+        f16x8 xn[SPR];
+        const bool more = y + 1 < y1;
+        if (more) {
+#pragma unroll
+            for (int sp = 0; sp < SPR; ++sp) fetch(ip + in_pitch + koff[KR - 1][sp], xn[sp]);
+        }
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < KR; ++ky)
+#pragma unroll
+            for (int sp = 0; sp < SPR; ++sp)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][ky * SPR + sp], xr[ky][sp], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const f32x4 v = acc[c] + bv[c];
+            const f16x4 t = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            const f16x4 h = __builtin_elementwise_max(t, lo4);
+            if (xvalid) *(f16x4*)(op + c * 16 + fk * 4) = h;
+        }
+        if (!more) break;
+        ip += in_pitch;
+        op += out_pitch;
+#pragma unroll
+        for (int ky = 0; ky + 1 < KR; ++ky)
+#pragma unroll
+            for (int sp = 0; sp < SPR; ++sp) xr[ky][sp] = xr[ky + 1][sp];
+#pragma unroll
+        for (int sp = 0; sp < SPR; ++sp) xr[KR - 1][sp] = xn[sp];
+    }
+}
+
 // fp32 NCHW (B,3,H,W) image -> padded NHWC4 fp16 (4th channel = 0): the stem's operand layout.
 __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, f16* __restrict__ out, int B, int H, int W,
                                                             int Hp, int Wp, int P) {
@@ -157,7 +261,18 @@ bool conv_smallc_supported(int cin, int cout, int ntaps) {
         hipLaunchKernelGGL((conv_smallc_kernel<CIN, NCT, S, TPW>), grid, block, 0, s, a);                    \
     } while (0)
 
+#define LAUNCH_ROWS(CIN, NCT, KR, SPR, R, GY)                                                                 \
+    do {                                                                                                     \
+        const int H = a.HmWm / a.Wm, B = a.M / a.HmWm;                                                       \
+        const int tiles_x = (a.Wm + 15) / 16, strips_y = (H + (R) - 1) / (R);                                \
+        const int nwaves = B * strips_y * tiles_x;                                                           \
+        dim3 grid((nwaves + 3) / 4, (GY), 1), block(256);                                                    \
+        hipLaunchKernelGGL((conv_smallc_rows_kernel<CIN, NCT, KR, SPR, R>), grid, block, 0, s, a, tiles_x, strips_y, nwaves); \
+    } while (0)
+
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s) {
+    if (a.in_stride == 1 && a.out_scale == 1 && a.cin == 4 && a.ntaps == 49 && a.cout == 16) { LAUNCH_ROWS(4, 1, 7, 1, 32, 1); return hipGetLastError(); }
+    if (a.in_stride == 1 && a.out_scale == 1 && a.cin == 16 && a.ntaps == 9 && a.cout == 16 && a.ksteps == 6) { LAUNCH_ROWS(16, 1, 3, 2, 32, 1); return hipGetLastError(); }
     if (a.cin == 16 && a.ntaps == 9 && a.cout == 16) LAUNCH(16, 1, 5, 8, 1);
     else if (a.cin == 16 && a.ntaps == 9 && a.cout == 32) LAUNCH(16, 2, 5, 8, 1);
     else if (a.cin == 32 && a.ntaps == 9 && a.cout == 64) LAUNCH(32, 2, 9, 8, 2);

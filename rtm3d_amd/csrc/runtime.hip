@@ -235,8 +235,12 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     } else if (d->kernel == 3) {
         if (d->groups != 1 || d->out_nchw_f32 || res) RT_FAIL("op_conv(smallc): groups/NCHW output/residual unsupported");
         if (!conv_smallc_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(smallc): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
-        const int S = d->cin == 16 ? 5 : (d->cin == 32 ? d->ntaps : 7);
+        int S = d->cin == 16 ? 5 : (d->cin == 32 ? d->ntaps : 7);
+        // cin=16 also comes packed by filter rows (6 k-steps: taps (ky,0),(ky,1) | (ky,2),zero) for the
+        // vertical-walk kernel of stride-1 layers; the blob size tells the two layouts apart
+        if (d->cin == 16 && d->cout == 16 && d->in_stride == 1 && d->out_scale == 1 && wbytes == (size_t)(d->cout / 16) * 6 * 64 * 8 * sizeof(f16)) S = 6;
         if (wbytes != (size_t)(d->cout / 16) * S * 64 * 8 * sizeof(f16)) RT_FAIL("op_conv(smallc): weight blob size mismatch");
+        a.ksteps = S;
         if (bbytes != (size_t)d->cout * sizeof(float)) RT_FAIL("op_conv(smallc): bias blob size mismatch");
         if (d->cin == 4 && in->P < 4) RT_FAIL("op_conv(smallc): the NHWC4 stem input needs a border of 4");
         a.g[0].w_off = 0; a.g[0].bias_off = 0;

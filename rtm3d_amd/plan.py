@@ -391,11 +391,21 @@ def pack_mfma_weights(wt, bn):
     return np.ascontiguousarray(w).astype(np.float16).reshape(-1), cout_pad
 
 
-def pack_smallc_weights(wt):
+def pack_smallc_weights(wt, rows=False):
     """wt: (taps, cout, cin) fp32 -> fp16 [cout/16][k-step][lane = fk*16 + row][8] for conv_smallc.hip.
-    cin=16: k-step s = taps (2s, 2s+1); cin=32: k-step = tap; cin=4: k-step = filter row of 7 taps
-    (+1 zero tap), lane group fk = taps (2fk, 2fk+1), 4 channels each."""
+    cin=16: k-step s = taps (2s, 2s+1), or with rows=True (stride-1 layers, vertical-walk kernel) two
+    k-steps per filter row: taps (ky,0),(ky,1) and (ky,2),zero; cin=32: k-step = tap; cin=4: k-step =
+    filter row of 7 taps (+1 zero tap), lane group fk = taps (2fk, 2fk+1), 4 channels each."""
     taps, cout, cin = wt.shape
+    if cin == 16 and rows:
+        out = np.zeros((cout // 16, 6, 4, 16, 8), np.float32)          # ct, s = ky*2 + half, fk, row, j
+        w = wt.reshape(taps, cout // 16, 16, cin)
+        for ky in range(3):
+            for fk in range(4):
+                out[:, ky * 2, fk] = w[ky * 3 + (fk >> 1)][:, :, (fk & 1) * 8:(fk & 1) * 8 + 8]
+                if fk < 2:
+                    out[:, ky * 2 + 1, fk] = w[ky * 3 + 2][:, :, (fk & 1) * 8:(fk & 1) * 8 + 8]
+        return np.ascontiguousarray(out).astype(np.float16).reshape(-1)
     S = 5 if cin == 16 else (taps if cin == 32 else 7)
     out = np.zeros((cout // 16, S, 4, 16, 8), np.float32)              # ct, s, fk, row, j
     w = wt.reshape(taps, cout // 16, 16, cin)
@@ -488,7 +498,8 @@ class RealizedPlan(object):
         elif variant == 3:
             assert G == 1
             d.kernel, d.bn_tile = 3, 0
-            d.w_blob, d.bias_blob = self._blob(pack_smallc_weights(op['w'][0])), self._blob(op['bias'][0])
+            rows = op['cin'] == 16 and op['cout'] == 16 and op['in_stride'] == 1 and op['out_scale'] == 1 and len(op['taps'][0]) == 9
+            d.w_blob, d.bias_blob = self._blob(pack_smallc_weights(op['w'][0], rows=rows)), self._blob(op['bias'][0])
         elif op['cin'] % 64 == 0:
             bn = op.get('bn_tile') or choose_bn_tile(op['cout'], M)
             packed, biases = [], []
