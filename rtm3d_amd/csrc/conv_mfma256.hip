@@ -234,20 +234,24 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // non-zero data they run at the rate the chip's power management allows (1.9 GHz in-kernel clock;
 // the same binary on all-zero activations: 1.64 PFLOP/s).
 #define CONV256_MAX_BIAS 2048
-// Operand reads as inline asm: the compiler's waitcnt pass treats a ds_read it can see as possibly
-// aliasing every pending global_load_lds and puts s_waitcnt vmcnt(0) in front of it, which would drain
-// the DMA pipeline in every phase; ordering against the DMA is what SEG_SYNC_N's counted vmcnt is for.
-// The reads' own completion is the lgkmcnt(0) in SEG_SYNC_N.
-#define DS_READ_B128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+// LDS-DMA as inline asm (m0 = LDS base of the wave's 1 KB run, one 16-byte piece per lane).  The compiler
+// must not know these write LDS: its waitcnt pass treats every visible ds_read as possibly aliasing a pending
+// LDS-DMA and puts s_waitcnt vmcnt(0) in front of it, draining the DMA ring in every phase; ordering against
+// the DMA is SEG_SYNC_N's counted vmcnt + barrier.  The operand reads stay ordinary loads so that the hazard
+// recogniser sees them (with the reads hidden in asm instead, a renamed accumulator's old registers can be
+// handed to a ds_read whose data lands before a queued MFMA has read them as SrcC: conv_mfma256_halo.hip).
+#define DMA16(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LOAD_X_N(SLOT)                                                                      \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
-        DS_READ_B128(xf[p][0], xaddr0, (SLOT) * HALF_ELEMS * 2 + p * 2048);                 \
-        DS_READ_B128(xf[p][1], xaddr1, (SLOT) * HALF_ELEMS * 2 + p * 2048);                 \
+        xf[p][0] = LDS_F16X8(xaddr0 + (SLOT) * HALF_ELEMS * 2 + p * 2048);                  \
+        xf[p][1] = LDS_F16X8(xaddr1 + (SLOT) * HALF_ELEMS * 2 + p * 2048);                  \
     }
 #define LOAD_W_N(dstf, SLOT)                                                                \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                         \
-        DS_READ_B128(dstf[c][0], waddr0, (SLOT) * HALF_ELEMS * 2 + c * 2048);               \
-        DS_READ_B128(dstf[c][1], waddr1, (SLOT) * HALF_ELEMS * 2 + c * 2048);               \
+        dstf[c][0] = LDS_F16X8(waddr0 + (SLOT) * HALF_ELEMS * 2 + c * 2048);                \
+        dstf[c][1] = LDS_F16X8(waddr1 + (SLOT) * HALF_ELEMS * 2 + c * 2048);                \
     }
 #define SEG_SYNC_N(VM)                                                                      \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                       \
@@ -259,8 +263,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                        \
         _Pragma("unroll") for (int c = 0; c < 2; ++c)                                       \
             _Pragma("unroll") for (int p = 0; p < 4; ++p)                                   \
-                acc[i][j][c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[c][kk], xf[p][kk], \
-                    (FIRST && kk == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j][c][p], 0, 0, 0); \
+                acc[i][j][c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[c][kk], xf[p][kk], acc[i][j][c][p], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     if (TAILBAR) __builtin_amdgcn_s_barrier();                                              \
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (v >= vtotal) return;
 
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
     const int rr = tid >> 3, cs = tid & 7;
     const float rcp_hw = 1.0f / (float)a.HmWm, rcp_w = 1.0f / (float)a.Wm;
     uint32_t xo_c[2][2], xo_n[2][2];        // DMA source offsets of the current / next tile
@@ -361,13 +365,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     xo_n[0][0] = xo_c[0][0]; xo_n[0][1] = xo_c[0][1]; xo_n[1][0] = xo_c[1][0]; xo_n[1][1] = xo_c[1][1];
     wb_n = wb_c; gi_n = gi_c; mt_n = mt_c; nt_n = nt_c; live_n = false;
 
-    f16* const dummy = lds + 2 * BUF_ELEMS;
     // stage half-tile `slot` of the K-tile kpos steps into the current tile (kpos >= T: next tile;
     // no next tile: same addresses into the dummy slot so the DMA count per phase stays constant)
     auto stage = [&](int slot, int kpos, int par) {
         const bool in_cur = kpos < T;
         const int k = in_cur ? kpos : kpos - T;
-        f16* dst = (in_cur || live_n) ? (lds + par * BUF_ELEMS + slot * HALF_ELEMS) : dummy;
+        const uint32_t dst0 = lds_base + (uint32_t)((in_cur || live_n) ? par * BUF_ELEMS + slot * HALF_ELEMS : 2 * BUF_ELEMS) * 2u;
         if (slot < 2) {
             const int tap = k / a.cpt, q = k - tap * a.cpt;
             const int koff = a.g[in_cur ? gi_c : gi_n].tap_off[tap] + q * 64;
@@ -375,14 +378,13 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             for (int i = 0; i < 2; ++i) {
                 const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
                 const f16* src = a.in + (size_t)xo + (ptrdiff_t)koff;
-                __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)(dst + (i * 512 + wave * 64) * 8), 16, 0, 0);
+                DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
             }
         } else {
             const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ws + (i * 512 + tid) * 8),
-                                                 (LDS_AS void*)(dst + (i * 512 + wave * 64) * 8), 16, 0, 0);
+                DMA16(ws + (i * 512 + tid) * 8, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
         }
     };
 
@@ -390,7 +392,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     const int frow = lane & 15, fk = lane >> 4;
     const int sw0 = ((0 * 4 + fk) ^ (frow & 7)) * 8, sw1 = ((1 * 4 + fk) ^ (frow & 7)) * 8;
     // LDS byte addresses (within a K-tile buffer) of this lane's operand rows, k-halves 0 and 1
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
     const uint32_t xrow_b0 = (uint32_t)(((wp * 64 + frow) * 64 + sw0) * 2), xrow_b1 = (uint32_t)(((wp * 64 + frow) * 64 + sw1) * 2);
     const uint32_t wrow_b0 = (uint32_t)(((wc * 32 + frow) * 64 + sw0) * 2), wrow_b1 = (uint32_t)(((wc * 32 + frow) * 64 + sw1) * 2);
     // after the permlane swap a lane stores channels [so, so+8) of its wave's 32-channel run
@@ -422,6 +423,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
                          : "=&v"(ticket), "=&s"(saved_exec) : "v"(off), "v"(inc), "s"(tile_ctr) : "memory");
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[i][j][c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int t = 0;
         STEP_N(24, 1, 0)
         if (wave == 0) {
@@ -496,6 +505,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
 }
 
+struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
+bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht);
+hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s);
+
 static int device_cu_count() {
     static int n = 0;
     if (!n) {
@@ -513,6 +526,9 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
     for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
     nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
     if (!a.res && a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
+        HaloTaps ht;
+        if ((a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
+            return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, s);
         const int chunk = (a.MT + 7) / 8;
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;

@@ -1,0 +1,348 @@
+// Halo-tile form of the persistent 256x256 implicit-GEMM convolution, for layers whose taps all lie
+// within +-1 pixel (the dilation-1 head conv: 4 groups x 256->256, 3x3).
+//
+// conv_mfma256.hip stages a 256-pixel x 64-channel operand half-tile pair once per (tap, chunk): every
+// input pixel crosses L2 -> LDS nine times per chunk, and the rows a tile needs for dy = +-1 are fetched
+// again from beyond L2 (they were the dy = 0 rows of a tile that ran a whole K loop earlier): measured
+// 14.1 GB of fabric traffic per launch for 4.0 GB of algorithmic bytes.  Here the output tile is an
+// 8 x 32 pixel block and a workgroup stages its (8+2) x (32+2) HALO of one 64-channel chunk ONCE
+// (43.5 KB, double-buffered); the nine taps of that chunk read shifted rows of it (the swizzle
+// chunk ^= pixel & 7 keeps ds_read_b128 conflict-free for every shift).  The K loop runs chunk-major
+// (kt = chunk * ntaps + tap) over the same packed weights (K-tile index tap * cpt + chunk).
+//   pixel operand DMA per 64-channel chunk: 43.5 KB instead of 9 x 32 KB; weights unchanged (9 x 32 KB).
+//
+// Schedule, tickets, bias-in-LDS, 16-byte swapped stores: as the persistent kernel of conv_mfma256.hip.
+// Differences: the weight ring holds only WA/WB half-tiles (64 KB); the halo of the NEXT chunk (or of the
+// next tile's first chunk) is staged in 2*ntaps equal slices, one DMA instruction per wave in each P2 and
+// P3 (<= 64 lanes active, source address computed on the fly from the slice index), so that every K-tile
+// issues the same 2+1+1+2 DMA instructions and the counted s_waitcnt stays an immediate (vmcnt(6)).
+// When there is no next tile the same instructions re-stage data of the current tile into ring slots
+// that are already free: no dummy slot (the LDS is full) and no run-time counts.  (First version: six
+// 512-lane halo DMAs on taps 0-2 and per-phase counts dispatched through a switch: the scalar code of
+// that dispatch made the load segments longer than the partner wave's MFMA segment, -19 %.)
+#include "common.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+#define HALF_ELEMS (128 * 64)                 // one weight half-tile: 128 rows x 64 halves = 16 KB
+#define WRING_ELEMS (4 * HALF_ELEMS)          // two K-tiles x (WA, WB)
+#define HALO_W 34
+#define HALO_PIX (10 * HALO_W)                // 340 pixels
+#define HALO_PIECES (HALO_PIX * 8)            // 2720 16-byte pieces per chunk
+#define HALO_BUF_PIECES 2880                  // buffer size: the 2*ntaps slices x 8 waves x PPW lanes may overrun the halo
+#define HALO_ELEMS (HALO_BUF_PIECES * 8)
+#define HALO_MAX_BIAS 1024
+
+// per group, all taps packed into one 64-bit word (4 bits per tap: dy+1 in bits 0-1, dx+1 in bits 2-3) that lives
+// in SGPRs for the whole tile: an s_load per K-tile would put its latency in front of the operand reads
+struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
+
+// LDS-DMA as inline asm (m0 = LDS base of the wave's run, one 16-byte piece per active lane).  The compiler
+// must not know these write LDS: its waitcnt pass treats every visible ds_read as possibly aliasing a pending
+// LDS-DMA and puts s_waitcnt vmcnt(0) in front of it, draining the DMA ring in every phase; ordering against
+// the DMA is SEG_SYNC's counted vmcnt + barrier.  The operand reads stay ordinary loads, so that the hazard
+// recogniser sees them: with the reads hidden in asm instead, the register allocator handed a renamed
+// accumulator's old registers to a ds_read whose data landed before a queued MFMA had read them as SrcC.
+#define DMA16(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
+#define LDS_F32X4(byte_addr) (*(const LDS_AS f32x4*)(uintptr_t)(byte_addr))
+
+__global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs a, const HaloTaps ht, const int groups, const int nbias,
+                                                                unsigned int* tile_ctr) {
+    __shared__ __attribute__((aligned(128))) f16 lds[WRING_ELEMS + 2 * HALO_ELEMS];
+    __shared__ __attribute__((aligned(16))) float lds_bias[HALO_MAX_BIAS + 4];     // + two ticket words
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wc = wave >> 1;
+    const int T = a.ksteps, NTAP = a.ntaps, CPT = a.cpt;
+    for (int i = tid; i < nbias; i += 512) lds_bias[i] = a.bias[i];
+
+    // tile list (as conv_mfma256_persistent_kernel): position v -> (group, pixel tile, channel tile)
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int chunk = (a.MT + 7) >> 3;
+    int mt_here = a.MT - xcd * chunk;
+    mt_here = mt_here < 0 ? 0 : (mt_here > chunk ? chunk : mt_here);
+    const int jbs = mt_here * a.NT;
+    const int vtotal = jbs * groups;
+    int* const lds_ticket = (int*)(lds_bias + HALO_MAX_BIAS);
+    const int last_draw = vtotal + per_xcd - 1;
+    if (tid == 0) {
+        const int t0 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        int t1 = t0;
+        if (t0 < vtotal) t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        if (t0 == last_draw || t1 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[0] = t0; lds_ticket[1] = t1;
+    }
+    __syncthreads();
+    const int v = __builtin_amdgcn_readfirstlane(lds_ticket[0]);
+    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
+    if (v >= vtotal) return;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
+    const int Hm = a.HmWm / a.Wm;
+    const int tiles_x = a.Wm >> 5, tpi = tiles_x * (Hm >> 3);      // 8 x 32 pixel tiles per image
+
+    // halo staging: 2*NTAP slices per chunk, slice = PPW pieces per wave x 8 waves (16-byte pieces)
+    // (rounded up to a multiple of 4 pieces = 64 bytes)
+    const int PPW = ((HALO_PIECES + 16 * NTAP - 1) / (16 * NTAP) + 3) & ~3;       // <= 64 for NTAP >= 3
+    const bool xlane_on = lane < PPW;
+
+    // tile descriptors (current / next): halo origin in the input tensor, weight base, indices
+    size_t xb_c, xb_n;                      // element offset of halo pixel (0,0), channel 0 of the group slice
+    const f16 *wb_c, *wb_n;
+    int gi_c, gi_n, nt_c, nt_n, n_c, n_n, ty_c, ty_n, tx_c, tx_n;
+    auto locate = [&](int vv, size_t& xb, const f16*& wb, int& gi, int& nt, int& n, int& ty, int& tx) {
+        gi = vv / jbs;
+        const int jb = vv - gi * jbs;
+        const int q = jb / a.NT;
+        nt = jb - q * a.NT;
+        const int mt = xcd * chunk + q;
+        n = mt / tpi;
+        const int r = mt - n * tpi;
+        ty = r / tiles_x;
+        tx = r - ty * tiles_x;
+        const ConvGroupArgs& g = a.g[gi];
+        xb = ((size_t)(n * a.in_Hp + ty * 8 - 1 + a.in_P) * a.in_Wp + tx * 32 - 1 + a.in_P) * a.in_C + g.in_coff;
+        wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
+    };
+    bool live_n = false;
+    locate(v, xb_c, wb_c, gi_c, nt_c, n_c, ty_c, tx_c);
+    xb_n = xb_c; wb_n = wb_c; gi_n = gi_c; nt_n = nt_c; n_n = n_c; ty_n = ty_c; tx_n = tx_c;
+
+    // halo slice s (0 .. 2*NTAP-1) of chunk ch of tile base xb into halo buffer hp
+    auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
+        const int p0 = (sidx * 8 + wave) * PPW;                    // first piece of this wave's run
+        // Every wave issues this instruction with its first PPW lanes in every call - a wave that skipped
+        // it would count one DMA less than vmcnt(6) assumes and read a weight tile before it has landed.
+        // Pieces past the halo re-read its last piece into the slack at the end of the buffer.
+        int p = p0 + lane;
+        p = p < HALO_PIECES ? p : HALO_PIECES - 1;
+        const int hq = p >> 3, hcs = p & 7;
+        const int hy = hq / HALO_W, hx = hq - hy * HALO_W;
+        // LDS position hcs of halo pixel (hy, hx) holds data chunk hcs ^ key, key = (hx ^ (hy << 2)) & 7:
+        // consecutive pixels of a row rotate through the banks, and a row step only flips bit 2
+        const uint32_t off = (uint32_t)((hy * a.in_Wp + hx) * a.in_C + ((hcs ^ ((hx ^ (hy << 2)) & 7)) * 8));
+        const f16* src = a.in + xb + ch * 64 + off;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + p0 * 8) * 2u);
+        if (xlane_on) DMA16(src, dst);
+    };
+    // weight half-tile (0 = WA, 1 = WB) with packed K-tile index kw of weight base wbp into ring buffer par
+    auto stage_w = [&](int half, const f16* wbp, int kw, int par) {
+        const f16* ws = wbp + (size_t)kw * (256 * 64) + half * HALF_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((par * 2 + half) * HALF_ELEMS + (i * 512 + wave * 64) * 8) * 2u);
+            DMA16(ws + (i * 512 + tid) * 8, dst);
+        }
+    };
+
+    f32x4 acc[2][2][2][4];     // [pixel half][W half][channel tile][pixel tile]
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw0 = ((0 * 4 + fk) ^ (frow & 7)) * 8, sw1 = ((1 * 4 + fk) ^ (frow & 7)) * 8;
+    const uint32_t wrow_b0 = (uint32_t)(((wc * 32 + frow) * 64 + sw0) * 2), wrow_b1 = (uint32_t)(((wc * 32 + frow) * 64 + sw1) * 2);
+    // halo byte offset of this lane's fragment (half 0, pixel tile 0) at tap (0,0): tile row wp*2, column frow;
+    // the other fragments are compile-time offsets from it, a tap adds shift*128 (wave-uniform)
+    const uint32_t xlane = (uint32_t)(((wp * 2 + 1) * HALO_W + frow + 1) * 128);
+    // swizzled 16-byte slot of this lane's k-chunk fk for the three column shifts dx = -1, 0, +1
+    // (the k-half 1 slot and an odd halo row are each the same slot ^ 64 bytes)
+    const uint32_t ck_m = (uint32_t)((((frow + 0) ^ fk) & 7) << 4), ck_0 = (uint32_t)((((frow + 1) ^ fk) & 7) << 4),
+                   ck_p = (uint32_t)((((frow + 2) ^ fk) & 7) << 4);
+    const int so_ch = (fk & 1) * 16 + (fk >> 1) * 8;
+    const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
+    const f16x4 lo4 = {lo, lo, lo, lo};
+
+    // ---- prologue (once per workgroup): halo of chunk 0, WA(0), WB(0), WA(1); everything lands
+    for (int sidx = 0; sidx < 2 * NTAP; ++sidx) stage_x(sidx, xb_c, 0, 0);
+    stage_w(0, wb_c, 0, 0);
+    stage_w(1, wb_c, 0, 0);
+    stage_w(0, wb_c, CPT, 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
+
+    f16x8 xf[4][2], wa[2][2], wb[2][2];
+    int sp = 0;                 // weight ring buffer of the current K-tile
+    int hpar = 0;               // halo buffer of the current chunk
+    int tpar = 0;
+
+#define LOAD_X_H(I)                                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                             \
+        /* halo row of fragment p = 1 + dy + I*4 + wp*2 + (p>>1): its parity swaps the two k-half slots */ \
+        const uint32_t a0 = (p >> 1) ? xw : xu, a1 = (p >> 1) ? xu : xw;                         \
+        xf[p][0] = LDS_F16X8(a0 + (((I) * 4 + (p >> 1)) * HALO_W + (p & 1) * 16) * 128);        \
+        xf[p][1] = LDS_F16X8(a1 + (((I) * 4 + (p >> 1)) * HALO_W + (p & 1) * 16) * 128);        \
+    }
+#define LOAD_W_H(dstf, HALF)                                                                    \
+    _Pragma("unroll") for (int cc = 0; cc < 2; ++cc) {                                          \
+        dstf[cc][0] = LDS_F16X8(wbuf + wrow_b0 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
+        dstf[cc][1] = LDS_F16X8(wbuf + wrow_b1 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
+    }
+#define SEG_SYNC_H(VM)                                                                          \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    __builtin_amdgcn_s_barrier();                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define MMA_H(i, j, wfrag, FIRST, TAILBAR)                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                            \
+        _Pragma("unroll") for (int cc = 0; cc < 2; ++cc)                                        \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p)                                       \
+                acc[i][j][cc][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[cc][kk], xf[p][kk], acc[i][j][cc][p], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (TAILBAR) __builtin_amdgcn_s_barrier();                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+// One K-tile (ch, tap).  K-tiles kt+1 / kt+2 = (ch1, tap1) / (ch2, tap2); a chunk index == CPT means chunk 0 of
+// the next tile (descriptor n, which aliases c when there is none: the re-staged data lands in free slots).
+#define STEP_H(VM, FIRST, LAST)                                                                 \
+    {                                                                                           \
+        const uint32_t hb = lds_base + (uint32_t)(WRING_ELEMS + hpar * HALO_ELEMS) * 2;          \
+        const uint32_t wbuf = lds_base + (uint32_t)sp * (2 * HALF_ELEMS * 2);                    \
+        const int tbits = (int)(tapword >> (4 * tap)) & 15;                                     \
+        const int dys = (tbits & 3) - 1, dxs = (tbits >> 2) - 1;                                 \
+        const uint32_t ck = dxs < 0 ? ck_m : (dxs > 0 ? ck_p : ck_0);                            \
+        const uint32_t xt0 = hb + xlane + (uint32_t)((dys * HALO_W + dxs) * 128) + ck;           \
+        const uint32_t xu = xt0 ^ (uint32_t)(((1 + dys) & 1) << 6), xw = xu ^ 64u;               \
+        int tap1 = tap + 1, ch1 = ch;                                                           \
+        if (tap1 == NTAP) { tap1 = 0; ch1 = ch + 1; }                                            \
+        int tap2 = tap1 + 1, ch2 = ch1;                                                         \
+        if (tap2 == NTAP) { tap2 = 0; ch2 = ch1 + 1; }                                           \
+        const bool xn = ch + 1 == CPT;               /* the halo staged now is the next tile's chunk 0 */ \
+        LOAD_X_H(0)                                                                             \
+        LOAD_W_H(wa, 0)                                                                         \
+        stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);       \
+        SEG_SYNC_H(VM)                                                                          \
+        MMA_H(0, 0, wa, FIRST, 1)                                                               \
+        LOAD_W_H(wb, 1)                                                                         \
+        stage_x(2 * tap, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                           \
+        SEG_SYNC_H(VM)                                                                          \
+        MMA_H(0, 1, wb, FIRST, 1)                                                               \
+        LOAD_X_H(1)                                                                             \
+        stage_x(2 * tap + 1, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                       \
+        SEG_SYNC_H(VM)                                                                          \
+        MMA_H(1, 1, wb, FIRST, 1)                                                               \
+        stage_w(0, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);   \
+        SEG_SYNC_H(VM)                                                                          \
+        MMA_H(1, 0, wa, FIRST, !(LAST))                                                         \
+        sp ^= 1;                                                                                \
+        if (++tap == NTAP) { tap = 0; ++ch; hpar ^= 1; }                                         \
+    }
+
+    for (;;) {
+        // ticket of the tile after next (see conv_mfma256_persistent_kernel)
+        int ticket = vnext;
+        const bool draw = vnext < vtotal;
+        if (wave == 0 && draw) {
+            const unsigned inc = 1u, off = (unsigned)xcd * 4u;
+            unsigned long long saved_exec;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                         : "=&v"(ticket), "=&s"(saved_exec) : "v"(off), "v"(inc), "s"(tile_ctr) : "memory");
+        }
+        // successor tile (its ticket was drawn a tile ago): its weights are staged from K-tile T-2 on, its
+        // halo during the last chunk - which is the first K-tile already when cin = 64
+        live_n = draw;
+        if (live_n) locate(vnext, xb_n, wb_n, gi_n, nt_n, n_n, ty_n, tx_n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[i][j][cc][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned long long tapword = ht.taps[gi_c];
+        int ch = 0, tap = 0;
+        STEP_H(22, 1, 0)                    // 6 + the previous tile's 16 stores
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(ticket) : : "memory");   // the atomic is older than this K-tile's 6 DMAs
+            if (lane == 0) {
+                lds_ticket[tpar] = ticket;
+                if (draw && ticket == last_draw) tile_ctr[xcd] = 0u;
+            }
+        }
+        for (int kt = 1; kt < T - 1; ++kt) STEP_H(6, 0, 0)
+        STEP_H(6, 0, 1)
+        // last MFMA segment had no trailing barrier: waves 0-3 take it before their epilogue, waves 4-7 after
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+
+        // ---- epilogue: 16 independent 16-byte stores, no loads from global memory
+        {
+            const ConvGroupArgs& g = a.g[gi_c];
+            const int cbase = g.out_coff + nt_c * 256 + wc * 32 + so_ch;
+            f32x4 bv[2][2];
+            {
+                const float* bp = lds_bias + g.bias_off + nt_c * 256 + wc * 32 + fk * 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) bv[j][cc] = *(const f32x4*)(bp + j * 128 + cc * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                size_t opix[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int oy = (ty_c * 8 + i * 4 + wp * 2 + (p >> 1)) * a.out_scale + g.out_oy;
+                    const int ox = (tx_c * 32 + (p & 1) * 16 + frow) * a.out_scale + g.out_ox;
+                    opix[p] = ((size_t)(n_c * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + cbase;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint32_t u[2][2];
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            const f32x4 vv = acc[i][j][cc][p] + bv[j][cc];
+                            f16x4 h = {(f16)vv[0], (f16)vv[1], (f16)vv[2], (f16)vv[3]};
+                            h = __builtin_elementwise_max(h, lo4);
+                            __builtin_memcpy(u[cc], &h, 8);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        *(u32x4*)((f16*)a.out + opix[p] + j * 128) = o;
+                    }
+            }
+        }
+        if (wave >= 4) __builtin_amdgcn_s_barrier();
+        if (!live_n) break;
+        vnext = __builtin_amdgcn_readfirstlane(lds_ticket[tpar]);
+        tpar ^= 1;
+        xb_c = xb_n;
+        wb_c = wb_n; gi_c = gi_n; nt_c = nt_n; n_c = n_n; ty_c = ty_n; tx_c = tx_n;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
+}
+
+// Eligibility: every tap within +-1 pixel, stride 1, 8 x 32 tiles cover the output exactly.
+bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
+    if (a.res || a.in_stride != 1 || a.in_P < 1 || a.ntaps > 9 || a.ntaps < 3) return false;
+    const int ppw = ((HALO_PIECES + 16 * a.ntaps - 1) / (16 * a.ntaps) + 3) & ~3;
+    if (ppw > 64 || 16 * a.ntaps * ppw > HALO_BUF_PIECES) return false;
+    if (a.Wm % 32 || (a.HmWm / a.Wm) % 8 || a.M % a.HmWm) return false;
+    const int pitch = a.in_Wp * a.in_C;
+    for (int g = 0; g < RT_MAX_GROUPS; ++g) ht->taps[g] = 0;
+    for (int g = 0; g < groups; ++g)
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int off = a.g[g].tap_off[t];
+            int dy = (off + pitch + pitch / 2) / pitch - 1;          // round(off / pitch) for |dy| <= 1
+            const int rem = off - dy * pitch;
+            if (rem % a.in_C) return false;
+            const int dx = rem / a.in_C;
+            if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+            ht->taps[g] |= (unsigned long long)((dy + 1) | ((dx + 1) << 2)) << (4 * t);
+        }
+    return true;
+}
+
+hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s) {
+    const int chunk = (a.MT + 7) / 8;
+    int per_xcd = cu_count / 8;
+    if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+    hipLaunchKernelGGL(conv_mfma256_halo_kernel, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr);
+    return hipGetLastError();
+}

@@ -84,6 +84,30 @@ def test_conv_kernels_vs_torch(case):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize('shape', [(1, 8, 32, 64, 1), (2, 16, 64, 256, 4), (3, 24, 96, 128, 2)])
+def test_halo_conv256_vs_torch(shape):
+    """3x3 dilation-1 convs whose output is covered by 8x32 tiles take the halo-tile kernel
+    (conv_mfma256_halo.hip): single and grouped, 1-4 chunks of 64 channels, several tiles per workgroup."""
+    B, H, W, cin, G = shape
+    rng = np.random.default_rng(B * 100 + cin)
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt = P.tensor(H, W, cin * G, 1)
+    yt = P.tensor(H, W, 256 * G, 1)
+    ws = [(rng.standard_normal((256, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32) for _ in range(G)]
+    bs = [rng.standard_normal(256).astype(np.float32) for _ in range(G)]
+    if G == 1:
+        P.conv(xt, yt, ws[0], bs[0], relu=True, name='t')
+    else:
+        P.grouped_conv([P.sub(xt, g * cin, cin) for g in range(G)], [P.sub(yt, g * 256, 256) for g in range(G)], ws, bs, relu=True, name='t')
+    P.ops[-1]['variant'] = 2
+    x = rng.standard_normal((B, cin * G, H, W)).astype(np.float32)
+    (got,), _ = _run(P, [(xt, x)], [yt])
+    ref = torch.cat([F.conv2d(h(torch.from_numpy(x[:, g * cin:(g + 1) * cin])), h(torch.from_numpy(ws[g])), torch.from_numpy(bs[g]), 1, 1)
+                     for g in range(G)], 1).relu()
+    ref = h(ref).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
 def test_persistent_conv_replays_identically():
     """The persistent conv kernel hands out tiles through per-XCD ticket counters that the last draw of a
     launch resets: ten replays of one context (and a second context in between) must all give the
