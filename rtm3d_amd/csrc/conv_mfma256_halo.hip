@@ -13,7 +13,7 @@
 //
 // Schedule, tickets, bias-in-LDS, 16-byte swapped stores: as the persistent kernel of conv_mfma256.hip.
 // Differences: the weight ring holds only WA/WB half-tiles (64 KB); the halo of the NEXT chunk (or of the
-// next tile's first chunk) is staged in 2*ntaps equal slices, one DMA instruction per wave in each P2 and
+// next tile's first chunk) is staged in 2*ntaps-1 equal slices, one DMA instruction per wave in each P2 and
 // P3 (<= 64 lanes active, source address computed on the fly from the slice index), so that every K-tile
 // issues the same 2+1+1+2 DMA instructions and the counted s_waitcnt stays an immediate (vmcnt(6)).
 // When there is no next tile the same instructions re-stage data of the current tile into ring slots
@@ -30,7 +30,7 @@
 #define HALO_W 34
 #define HALO_PIX (10 * HALO_W)                // 340 pixels
 #define HALO_PIECES (HALO_PIX * 8)            // 2720 16-byte pieces per chunk
-#define HALO_BUF_PIECES 2880                  // buffer size: the 2*ntaps slices x 8 waves x PPW lanes may overrun the halo
+#define HALO_BUF_PIECES 2912                  // buffer size: the (2*ntaps-1) slices x 8 waves x PPW lanes may overrun the halo
 #define HALO_ELEMS (HALO_BUF_PIECES * 8)
 #define HALO_MAX_BIAS 1024
 
@@ -85,9 +85,16 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const int Hm = a.HmWm / a.Wm;
     const int tiles_x = a.Wm >> 5, tpi = tiles_x * (Hm >> 3);      // 8 x 32 pixel tiles per image
 
-    // halo staging: 2*NTAP slices per chunk, slice = PPW pieces per wave x 8 waves (16-byte pieces)
-    // (rounded up to a multiple of 4 pieces = 64 bytes)
-    const int PPW = ((HALO_PIECES + 16 * NTAP - 1) / (16 * NTAP) + 3) & ~3;       // <= 64 for NTAP >= 3
+    // halo staging: 2*NTAP - 1 slices per chunk, slice = PPW pieces per wave x 8 waves (16-byte pieces, PPW
+    // rounded up to a multiple of 4 = 64 bytes).  The 2*NTAP-th slot (P3 of the chunk's last tap) re-stages
+    // slice 0: what is issued there may still be in flight when the next chunk's first K-tile reads its
+    // operands (a read in phase p is covered by the wait of phase p-1, which lets the DMA of the four
+    // phases before it stay pending), so it must not carry anything new.  The last real slice (P2 of the
+    // last tap) holds the bottom halo row, first read in P3 of that K-tile: covered.  (With data in the last
+    // slot the transposed-conv phases, whose first tap reads the bottom row at once, were not
+    // bit-reproducible.)
+    const int NSL = 2 * NTAP - 1;
+    const int PPW = ((HALO_PIECES + 8 * NSL - 1) / (8 * NSL) + 3) & ~3;           // <= 64 for NTAP >= 4
     const bool xlane_on = lane < PPW;
 
     // tile descriptors (current / next): halo origin in the input tensor, weight base, indices
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
     // halo slice s (0 .. 2*NTAP-1) of chunk ch of tile base xb into halo buffer hp
     auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
-        const int p0 = (sidx * 8 + wave) * PPW;                    // first piece of this wave's run
+        const int p0 = ((sidx == NSL ? 0 : sidx) * 8 + wave) * PPW;   // first piece of this wave's run
         // Every wave issues this instruction with its first PPW lanes in every call - a wave that skipped
         // it would count one DMA less than vmcnt(6) assumes and read a weight tile before it has landed.
         // Pieces past the halo re-read its last piece into the slack at the end of the buffer.
@@ -320,9 +327,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
 // Eligibility: every tap within +-1 pixel, stride 1, 8 x 32 tiles cover the output exactly.
 bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
-    if (a.res || a.in_stride != 1 || a.in_P < 1 || a.ntaps > 9 || a.ntaps < 3) return false;
-    const int ppw = ((HALO_PIECES + 16 * a.ntaps - 1) / (16 * a.ntaps) + 3) & ~3;
-    if (ppw > 64 || 16 * a.ntaps * ppw > HALO_BUF_PIECES) return false;
+    if (a.res || a.in_stride != 1 || a.in_P < 1 || a.ntaps > 9 || a.ntaps < 4) return false;
+    const int nsl = 2 * a.ntaps - 1;
+    const int ppw = ((HALO_PIECES + 8 * nsl - 1) / (8 * nsl) + 3) & ~3;
+    if (ppw > 64 || 8 * nsl * ppw > HALO_BUF_PIECES) return false;
     if (a.Wm % 32 || (a.HmWm / a.Wm) % 8 || a.M % a.HmWm) return false;
     const int pitch = a.in_Wp * a.in_C;
     for (int g = 0; g < RT_MAX_GROUPS; ++g) ht->taps[g] = 0;
