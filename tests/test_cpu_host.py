@@ -157,3 +157,39 @@ def test_all_gather_records_gloo_world2():
         assert p.exitcode == 0
     res = dict(q.get() for _ in range(2))
     assert res[0] == res[1]           # every rank holds the same gathered batch
+
+
+def test_box_projection_matches_reference_golden_vectors():
+    """n3: rotation_matrix / create_corners / calc_proj_corners against the vectors produced by running the
+    reference (tests/golden/make_golden_project.py), incl. yaw values inside its 1e-3 snapping window."""
+    from rtm3d_amd import kitti_results as kr
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'project_cases.npz'))
+    for i in range(len(g['Ry'])):
+        c = kr.create_corners(g['dimension'][i], g['location'][i], kr.rotation_matrix(g['Ry'][i]))
+        np.testing.assert_array_equal(c, g['corners'][i])
+        p = kr.calc_proj_corners(g['dimension'][i], g['location'][i], g['Ry'][i], g['K'])
+        np.testing.assert_array_equal(p, g['proj'][i])
+
+
+def test_kitti_label_lines(tmp_path):
+    from rtm3d_amd import kitti_results as kr
+    from rtm3d_amd.ParamList import ParamList
+    K = np.array([[721.5377, 0.0, 609.5593], [0.0, 721.5377, 172.854], [0.0, 0.0, 1.0]])
+    pl = ParamList((1280, 384))
+    pl.add_field('class', [0, 2]); pl.add_field('Ry', [0.3, -1.2])
+    pl.add_field('dimension', [[1.5, 1.6, 3.9], [1.7, 0.6, 1.8]]); pl.add_field('location', [[2.0, 1.0, 20.0], [-60.0, 1.0, 10.0]])
+    pl.add_field('K', [K.reshape(-1), K.reshape(-1)])
+    lines = kr.kitti_label_lines(pl, image_size=(1280, 384))
+    assert len(lines) == 2
+    a = lines[0].split()
+    assert a[0] == 'Car' and len(a) == 16
+    assert abs(float(a[12]) - (1.0 + 0.75)) < 1e-9            # bottom-face y = centre y + h/2
+    assert abs(float(a[3]) - (0.3 - np.arctan2(2.0, 20.0))) < 5e-3
+    assert [float(v) for v in a[8:11]] == [1.5, 1.6, 3.9]
+    proj, boxes = kr.project_boxes(pl)
+    assert proj.shape == (2, 9, 2) and abs(float(a[4]) - boxes[0, 0]) < 5e-3
+    b = lines[1].split()
+    assert b[0] == 'Cyclist' and float(b[4]) == 0.0           # clipped to the image
+    n = kr.write_kitti_label_file(str(tmp_path / 'data' / '000001.txt'), pl)
+    assert n == 2 and len(open(str(tmp_path / 'data' / '000001.txt')).read().splitlines()) == 2
+    assert kr.write_kitti_label_file(str(tmp_path / 'data' / '000002.txt'), None) == 0
