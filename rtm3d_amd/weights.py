@@ -47,7 +47,11 @@ def parse_backbone(name):
     if 'RESNET' in name:
         n = int(name.split('-')[-1])
         if n not in RESNET_BLOCKS:
-            raise NotImplementedError('only BasicBlock ResNets (18/34) are built; got %s' % name)
+            # The reference itself cannot run these: PoseResNet._kfpn_spec (models/nets/resnet.py:129-137) ignores
+            # Bottleneck.expansion, so the neck's 1x1 convs are built for 64..512 input channels and receive
+            # 256..2048 (RuntimeError in kfpn_head on the first forward).  There is no behaviour to match.
+            raise NotImplementedError('only the BasicBlock ResNets (18/34) exist as runnable models in the reference; '
+                                      '%s raises in its neck there (kfpn_spec ignores Bottleneck.expansion)' % name)
         return 'resnet', n
     raise AssertionError('Undefined model backbone')
 
