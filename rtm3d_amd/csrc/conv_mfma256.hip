@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent form (default when there is no residual operand and the K loop has >= 4 tiles).
+// Persistent form (default when the K loop has >= 4 tiles).
 // One workgroup per CU draws output tiles from its XCD's list (ticket counter):
 //   * the half-tile DMA pipeline runs straight across tile boundaries: the last two K-tiles of a
 //     tile already stage the first two of the next one (descriptor "n"), so there is no prologue,
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         sp ^= 1;                                                                            \
     }
 
+template <int RES>
 __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS + 4];   // + two ticket words
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 size_t opix[4];
+                f16x4 rv[4][2][2];       // residual (RES): loaded for the whole half before its first store
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     // rows past M were staged from pixel M-1 and hold its result: a same-value write
@@ -474,6 +476,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                     const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
                     const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
                     opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + cbase;
+                    if (RES) {
+                        const f16* rp = a.res + ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C
+                                        + g.res_coff + nt_c * 256 + wc * 32 + fk * 4;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) rv[p][j][c] = *(const f16x4*)(rp + j * 128 + c * 16);
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -482,7 +492,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                         uint32_t u[2][2];
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            const f32x4 vv = acc[i][j][c][p] + bv[j][c];       // same order as the other conv kernels
+                            f32x4 vv = acc[i][j][c][p] + bv[j][c];       // same order as the other conv kernels
+                            if (RES) {
+                                const f16x4 r = rv[p][j][c];
+                                vv[0] += (float)r[0]; vv[1] += (float)r[1]; vv[2] += (float)r[2]; vv[3] += (float)r[3];
+                            }
                             f16x4 h = {(f16)vv[0], (f16)vv[1], (f16)vv[2], (f16)vv[3]};
                             h = __builtin_elementwise_max(h, lo4);       // ReLU (or -inf) on packed halves
                             __builtin_memcpy(u[c], &h, 8);
@@ -525,15 +539,16 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
     int nbias = 0;
     for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
     nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
-    if (!a.res && a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
+    if (a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
         HaloTaps ht;
-        if ((a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
+        if (!a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
             return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, s);
         const int chunk = (a.MT + 7) / 8;
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
         dim3 grid(per_xcd * 8, 1, 1);
-        hipLaunchKernelGGL(conv_mfma256_persistent_kernel, grid, block, 0, s, a, groups, nbias, tile_ctr);
+        if (a.res) hipLaunchKernelGGL(conv_mfma256_persistent_kernel<1>, grid, block, 0, s, a, groups, nbias, tile_ctr);
+        else hipLaunchKernelGGL(conv_mfma256_persistent_kernel<0>, grid, block, 0, s, a, groups, nbias, tile_ctr);
         return hipGetLastError();
     }
     const int mt8 = (a.MT + 7) / 8 * 8;

@@ -366,9 +366,11 @@ def choose_variant(cin, cout, M, groups, out_nchw):
     if cin % 64:
         return 3 if cin in (4, 16, 32) else 1
     if not out_nchw and cout % 256 == 0:
-        # one workgroup per CU (256 CUs): at least two full rounds.  (A single nearly full round - DLA
-        # level4, 240 tiles - is 25 % faster per launch but loses 1.3 % end to end: early in the forward the
-        # 3D decode of the previous batch is still resident and cannot share a SIMD with this kernel.)
+        # one persistent workgroup per CU (256 CUs): at least two full rounds.  (A single nearly full round -
+        # DLA level4, 240 tiles - is 0.1 ms faster per forward on its own but 0.4 ms slower per pipelined
+        # step, measured twice (one-tile and persistent kernel): early in the forward the 3D decode of the
+        # previous batch still holds ~60 CUs, whose waves cannot share a SIMD with this kernel, and with one
+        # tile per CU there is nothing for the ticket scheduler to rebalance.)
         if ((M + 255) // 256) * (cout // 256) * groups >= 512:
             return 2
     return 0
