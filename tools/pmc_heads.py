@@ -8,7 +8,7 @@ KERNEL = ('conv_mfma256_persistent_kernel', 'conv_mfma256_halo_kernel')
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith(KERNEL)]
+        rows = [r for r in csv.DictReader(open(f)) if any(k in r['Kernel_Name'] for k in KERNEL)]
         per_counter = collections.defaultdict(list)
         for r in rows:
             per_counter[r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
