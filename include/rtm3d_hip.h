@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 1
+#define RTM3D_ABI_VERSION 2
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -86,6 +86,12 @@ typedef struct rtm3d_conv_desc {
     int bn_tile;                           /* MFMA: cout tile the weights were packed for (16/32/64/128) */
     int out_nchw_f32;                      /* 0, or 1..4 = index+1 into rtm3d_forward's out_logits[] */
     int out_H, out_W;                      /* only for out_nchw_f32 */
+    int softmax_stat_slot;                 /* -1, or 0..2: the output map is operand u[slot] of the NEXT rtm3d_op_softmax_fuse and this
+                                              launch also emits its spatial-softmax partials (per channel max / sum exp over each
+                                              128-pixel run) from the epilogue, so the fusion does not re-read the map to reduce it
+                                              (keypoint_fpn_fusion.py:67).  Only for kernel = 2 launches that take the halo-tile kernel
+                                              (taps within +-1 pixel, stride 1, Hm % 8 == 0, Wm % 32 == 0) with cout = 256 written at
+                                              channel offset 0 of a 256-channel tensor; anything else is refused. */
 } rtm3d_conv_desc;
 int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
 

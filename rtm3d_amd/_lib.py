@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_GROUPS, MAX_TAPS = 4, 49
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -30,6 +30,7 @@ class ConvDesc(ctypes.Structure):
         ('w_blob', c_int), ('bias_blob', c_int),
         ('kernel', c_int), ('bn_tile', c_int),
         ('out_nchw_f32', c_int), ('out_H', c_int), ('out_W', c_int),
+        ('softmax_stat_slot', c_int),
     ]
 
 

@@ -82,6 +82,7 @@ struct SoftmaxKArgs {
     float* partial;                // [n_u][B][chunks][C][2] (max, sumexp)
     float* stats;                  // [n_u][B][C][2] (max, 1/sum)
     int chunks, rows_per_chunk;
+    int partial_chunks;            // > 0: `partial` was written by the producers' epilogues with this many chunks per image
 };
 
 struct HeadOutArgs {
@@ -99,7 +100,8 @@ struct HeadOutArgs {
 // kernel launchers (each returns hipGetLastError())
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
-hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, hipStream_t s);
+hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s);
+bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);
 bool conv_smallc_supported(int cin, int cout, int ntaps);
 hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s);

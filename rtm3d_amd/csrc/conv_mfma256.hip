@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 
 struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht);
-hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s);
+hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, float* stat_out, hipStream_t s);
 
 static int device_cu_count() {
     static int n = 0;
@@ -534,7 +534,17 @@ static int device_cu_count() {
     return n;
 }
 
-hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, hipStream_t s) {
+// Whether launch_conv_mfma256 sends this conv to the halo-tile kernel (the only one that can emit the
+// spatial-softmax partials of its output, `stat_out`).
+bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups) {
+    int nbias = 0;
+    for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
+    nbias = (nbias + 255) / 256 * 256;
+    HaloTaps ht;
+    return a.ksteps >= 4 && !a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht);
+}
+
+hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s) {
     dim3 block(512, 1, 1);
     int nbias = 0;
     for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
@@ -542,7 +552,8 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
     if (a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
         HaloTaps ht;
         if (!a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
-            return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, s);
+            return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, stat_out, s);
+        if (stat_out) return hipErrorInvalidValue;   // only the halo kernel writes softmax partials
         const int chunk = (a.MT + 7) / 8;
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
@@ -551,6 +562,7 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
         else hipLaunchKernelGGL(conv_mfma256_persistent_kernel<0>, grid, block, 0, s, a, groups, nbias, tile_ctr);
         return hipGetLastError();
     }
+    if (stat_out) return hipErrorInvalidValue;       // only the halo kernel writes softmax partials
     const int mt8 = (a.MT + 7) / 8 * 8;
     dim3 grid(mt8 * a.NT, groups, 1);
     if (a.res) hipLaunchKernelGGL((conv_mfma256_kernel<1>), grid, block, 0, s, a);

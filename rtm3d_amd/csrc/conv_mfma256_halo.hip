@@ -49,8 +49,9 @@ struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LDS_F32X4(byte_addr) (*(const LDS_AS f32x4*)(uintptr_t)(byte_addr))
 
+template <int STATS>
 __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs a, const HaloTaps ht, const int groups, const int nbias,
-                                                                unsigned int* tile_ctr) {
+                                                                unsigned int* tile_ctr, float* stat_out) {
     __shared__ __attribute__((aligned(128))) f16 lds[WRING_ELEMS + 2 * HALO_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[HALO_MAX_BIAS + 4];     // + two ticket words
     const int tid = threadIdx.x;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 #pragma unroll
                     for (int cc = 0; cc < 2; ++cc) bv[j][cc] = *(const f32x4*)(bp + j * 128 + cc * 16);
             }
+            f16x4 hq[2][4][2][2];          // fp16 results [pixel half][pixel tile][channel half][channel tile]
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 size_t opix[4];
@@ -306,12 +308,63 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                             const f32x4 vv = acc[i][j][cc][p] + bv[j][cc];
                             f16x4 h = {(f16)vv[0], (f16)vv[1], (f16)vv[2], (f16)vv[3]};
                             h = __builtin_elementwise_max(h, lo4);
+                            if (STATS) hq[i][p][j][cc] = h;
                             __builtin_memcpy(u[cc], &h, 8);
                         }
                         const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         *(u32x4*)((f16*)a.out + opix[p] + j * 128) = o;
+                    }
+            }
+            if (STATS) {
+                // Spatial-softmax partials of this wave's 128 pixels x 64 channels (keypoint_fpn_fusion.py:67: the
+                // fusion then needs no pass over the map to find them): per channel the max and sum exp(v - max)
+                // of the STORED fp16 values.  Lane (frow, fk) holds pixels (i, p, frow) x channels (j, cc, fk*4+e):
+                // reduce over (i, p) in the lane, over frow with row rotations (DPP); lanes frow == 0 write.
+                // Layout [image][chunk = (group * tiles_per_image + tile) * 2 + wp][256 channels][max, sum].
+#define ROW_ROR_MAX(N)                                                                                           \
+    {                                                                                                            \
+        const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mu[d], 0x120 + (N), 0xf, 0xf, false);  \
+        f16x2 a_, b_;                                                                                            \
+        __builtin_memcpy(&a_, &mu[d], 4); __builtin_memcpy(&b_, &o_, 4);                                         \
+        a_ = __builtin_elementwise_max(a_, b_);                                                                  \
+        __builtin_memcpy(&mu[d], &a_, 4);                                                                        \
+    }
+#define ROW_ROR_ADD(N) S[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, S[e]), 0x120 + (N), 0xf, 0xf, false));
+                const size_t chunk = (size_t)(gi_c * tpi + ty_c * tiles_x + tx_c) * 2 + wp;
+                float* const srow = stat_out + (((size_t)n_c * (groups * tpi * 2) + chunk) * 256 + wc * 32 + fk * 4) * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        f16x4 mx = hq[0][0][j][cc];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) mx = __builtin_elementwise_max(mx, hq[i][p][j][cc]);
+                        uint32_t mu[2];
+                        __builtin_memcpy(mu, &mx, 8);
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) { ROW_ROR_MAX(8) ROW_ROR_MAX(4) ROW_ROR_MAX(2) ROW_ROR_MAX(1) }
+                        __builtin_memcpy(&mx, mu, 8);
+                        const f32x4 M = {(float)mx[0], (float)mx[1], (float)mx[2], (float)mx[3]};
+                        float S[4] = {0.f, 0.f, 0.f, 0.f};     // (scalars: update_dpp on ext-vector elements was miscompiled)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                const f16x4 h = hq[i][p][j][cc];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) S[e] += __expf((float)h[e] - M[e]);
+                            }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ROW_ROR_ADD(8) ROW_ROR_ADD(4) ROW_ROR_ADD(2) ROW_ROR_ADD(1) }
+                        if (frow == 0) {
+                            float* o = srow + (j * 128 + cc * 16) * 2;
+                            *(f32x4*)o = (f32x4){M[0], S[0], M[1], S[1]};
+                            *(f32x4*)(o + 4) = (f32x4){M[2], S[2], M[3], S[3]};
+                        }
                     }
             }
         }
@@ -347,10 +400,11 @@ bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
     return true;
 }
 
-hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s) {
+hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, float* stat_out, hipStream_t s) {
     const int chunk = (a.MT + 7) / 8;
     int per_xcd = cu_count / 8;
     if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
-    hipLaunchKernelGGL(conv_mfma256_halo_kernel, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr);
+    if (stat_out) hipLaunchKernelGGL(conv_mfma256_halo_kernel<1>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+    else hipLaunchKernelGGL(conv_mfma256_halo_kernel<0>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
     return hipGetLastError();
 }

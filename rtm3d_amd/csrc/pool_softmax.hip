@@ -86,18 +86,31 @@ __global__ __launch_bounds__(256) void softmax_reduce_kernel(const SoftmaxKArgs 
 }
 
 // pass 2: combine the per-chunk partials once per (u, image, channel): stats[u][b][c] = (max, 1/sum)
-__global__ __launch_bounds__(256) void softmax_combine_kernel(const SoftmaxKArgs a) {
-    const int n = blockIdx.x, ui = blockIdx.y, c = threadIdx.x;
-    const float* p = a.partial + (((size_t)ui * a.B + n) * a.chunks * a.C + c) * 2;
-    float mm = -INFINITY;
-    for (int k = 0; k < a.chunks; ++k) mm = fmaxf(mm, p[(size_t)k * a.C * 2]);
-    float ssum = 0.f;
-    for (int k = 0; k < a.chunks; ++k) {
-        const float mk = p[(size_t)k * a.C * 2];
-        if (mk != -INFINITY) ssum += p[(size_t)k * a.C * 2 + 1] * __expf(mk - mm);
+__global__ __launch_bounds__(1024) void softmax_combine_kernel(const SoftmaxKArgs a) {
+    // 4 x 256 threads: thread (part, c) folds the chunks k = part (mod 4) of channel c in one pass, LDS folds the four
+    const int n = blockIdx.x, ui = blockIdx.y, c = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const int chunks = a.partial_chunks > 0 ? a.partial_chunks : a.chunks;
+    const float2* p = (const float2*)a.partial + ((size_t)ui * a.B + n) * chunks * a.C + c;
+    float m = -INFINITY, sum = 0.f;
+    for (int k = part; k < chunks; k += 4) {
+        const float2 v = p[(size_t)k * a.C];
+        if (v.x != -INFINITY) {
+            const float mn = fmaxf(m, v.x);
+            sum = sum * __expf(m - mn) + v.y * __expf(v.x - mn);
+            m = mn;
+        }
     }
-    float* o = a.stats + (((size_t)ui * a.B + n) * a.C + c) * 2;
-    o[0] = mm; o[1] = 1.f / ssum;
+    __shared__ float sm[4][256], ss[4][256];
+    sm[part][c] = m; ss[part][c] = sum;
+    __syncthreads();
+    if (part == 0) {
+        const float mm = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += (sm[w][c] == -INFINITY) ? 0.f : ss[w][c] * __expf(sm[w][c] - mm);
+        float* o = a.stats + (((size_t)ui * a.B + n) * a.C + c) * 2;
+        o[0] = mm; o[1] = 1.f / t;
+    }
 }
 
 // pass 3: z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i      (16-byte lanes, two pixels in flight per lane)
@@ -152,8 +165,9 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
 
 hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s) {
     if (a.C != 256 || a.n_u < 1 || a.n_u > 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(softmax_reduce_kernel, dim3(a.chunks, a.B, a.n_u), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(softmax_combine_kernel, dim3(a.B, a.n_u, 1), dim3(256), 0, s, a);
+    // pass 1 is skipped when the producing convolutions emitted the partials from their epilogues
+    if (a.partial_chunks <= 0) hipLaunchKernelGGL(softmax_reduce_kernel, dim3(a.chunks, a.B, a.n_u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(softmax_combine_kernel, dim3(a.B, a.n_u, 1), dim3(1024), 0, s, a);
     if (a.n_u == 3) hipLaunchKernelGGL(softmax_apply_kernel<3>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
     else if (a.n_u == 2) hipLaunchKernelGGL(softmax_apply_kernel<2>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(softmax_apply_kernel<1>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);

@@ -34,6 +34,7 @@ struct Op {
     std::string name;
     double flops, bytes;
     ConvKArgs conv; int groups, bn_tile, epi_nchw, out_slot, ksize;
+    float* stat_out = nullptr;      // softmax partials written by this conv's epilogue (halo kernel), or null
     StemKArgs stem; int stem_cout;
     PoolKArgs pool;
     SoftmaxKArgs sm;
@@ -47,6 +48,10 @@ struct rtm3d_ctx {
     std::vector<size_t> blob_bytes;
     std::vector<Op> ops;
     std::vector<void*> extra;   // other device allocations (softmax partials)
+    // spatial-softmax partials emitted by conv epilogues for the next softmax op (softmax_stat_slot)
+    float* stat_buf = nullptr;
+    int stat_chunks = 0, stat_B = 0;
+    int stat_tensor[3] = {-1, -1, -1};
     unsigned int* tile_ctr = nullptr;   // 8 per-XCD ticket counters of the persistent conv kernel (self-resetting)
     // live probe: hipEvent pairs around one op of every replay (bench.py roofline)
     int probe_op = -1;
@@ -200,6 +205,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[g].out_oy = d->out_oy[g]; a.g[g].out_ox = d->out_ox[g];
     }
     op.groups = d->groups; op.epi_nchw = d->out_nchw_f32 ? 1 : 0; op.out_slot = d->out_nchw_f32 - 1;
+    int stat_slot = -1;
     const double M = (double)a.M;
     op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
     op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0);
@@ -212,6 +218,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         if (bbytes != (size_t)d->cout * d->groups * sizeof(float)) RT_FAIL("op_conv(mfma256): bias blob size mismatch");
         for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = d->cout * g; }
         op.kind = OP_CONV_MFMA256; op.bn_tile = 256;
+        stat_slot = d->softmax_stat_slot;
         if (!ctx->tile_ctr) {
             RT_HIP(hipMalloc((void**)&ctx->tile_ctr, 8 * sizeof(unsigned int)));
             RT_HIP(hipMemset(ctx->tile_ctr, 0, 8 * sizeof(unsigned int)));
@@ -254,6 +261,24 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[0].w_off = 0; a.g[0].bias_off = 0;
         op.kind = OP_CONV_DIRECT;
         op.name = "conv_direct_dot2";
+    }
+    if (d->softmax_stat_slot >= 0 && stat_slot < 0) RT_FAIL("op_conv: softmax_stat_slot needs kernel = 2");
+    if (stat_slot >= 0) {
+        // epilogue-emitted spatial-softmax partials: [slot][image][chunk][256][2] floats, chunk = 128-pixel run
+        if (stat_slot > 2) RT_FAIL("op_conv: softmax_stat_slot out of range");
+        if (!conv_mfma256_uses_halo(a, d->groups)) RT_FAIL("op_conv: softmax_stat_slot set on a conv that does not take the halo-tile kernel");
+        if (d->cout != 256 || out->C != 256) RT_FAIL("op_conv: softmax partials need a 256-channel output tensor");
+        for (int g = 0; g < d->groups; ++g) if (d->out_coff[g] != 0) RT_FAIL("op_conv: softmax partials need output channel offset 0");
+        const int chunks = d->groups * (d->Hm / 8) * (d->Wm / 32) * 2;
+        if (!ctx->stat_buf) {
+            RT_HIP(hipMalloc((void**)&ctx->stat_buf, (size_t)3 * in->B * chunks * 256 * 2 * sizeof(float)));
+            ctx->extra.push_back(ctx->stat_buf);
+            ctx->stat_chunks = chunks; ctx->stat_B = in->B;
+        } else if (ctx->stat_chunks != chunks || ctx->stat_B != in->B) {
+            RT_FAIL("op_conv: softmax partial producers of one fusion must have equal shapes");
+        }
+        ctx->stat_tensor[stat_slot] = d->out_tensor;
+        op.stat_out = ctx->stat_buf + (size_t)stat_slot * in->B * chunks * 256 * 2;
     }
     ctx->ops.push_back(op);
     return 0;
@@ -339,10 +364,23 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
     }
     a.rows_per_chunk = 2;
     a.chunks = (a.H + a.rows_per_chunk - 1) / a.rows_per_chunk;
-    void* part = nullptr;
-    RT_HIP(hipMalloc(&part, (size_t)n_u * a.B * a.chunks * a.C * 2 * sizeof(float)));
-    ctx->extra.push_back(part);
-    a.partial = (float*)part;
+    // partials already emitted by the producers' epilogues (rtm3d_conv_desc.softmax_stat_slot)?
+    bool emitted = ctx->stat_buf != nullptr && ctx->stat_B == a.B;
+    for (int i = 0; i < n_u && emitted; ++i) emitted = ctx->stat_tensor[i] == u_tensors[i];
+    for (int i = 0; i < 3; ++i) if ((i < n_u) != (ctx->stat_tensor[i] >= 0) && ctx->stat_buf) emitted = false;
+    if (ctx->stat_buf && !emitted) RT_FAIL("op_softmax_fuse: the recorded softmax_stat_slot producers do not match this fusion's operands");
+    if (emitted) {
+        a.partial = ctx->stat_buf;
+        a.partial_chunks = ctx->stat_chunks;
+        ctx->stat_buf = nullptr;                       // consumed (the allocation stays owned by ctx->extra)
+        ctx->stat_tensor[0] = ctx->stat_tensor[1] = ctx->stat_tensor[2] = -1;
+    } else {
+        void* part = nullptr;
+        RT_HIP(hipMalloc(&part, (size_t)n_u * a.B * a.chunks * a.C * 2 * sizeof(float)));
+        ctx->extra.push_back(part);
+        a.partial = (float*)part;
+        a.partial_chunks = 0;
+    }
     void* st = nullptr;
     RT_HIP(hipMalloc(&st, (size_t)n_u * a.B * a.C * 2 * sizeof(float)));
     ctx->extra.push_back(st);
@@ -362,7 +400,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
             e = launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
             break;
         }
-        case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, s); break;
+        case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
         case OP_HEADOUT: {

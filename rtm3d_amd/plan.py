@@ -461,8 +461,48 @@ class RealizedPlan(object):
             tid = ctypes.c_int()
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'], t['pad'], ctypes.byref(tid)), 'tensor_create')
             self.tids.append(tid.value)
-        for op in plan.ops:
+        self._stat_slots = self._softmax_stat_producers()
+        for k, op in enumerate(plan.ops):
+            self._k = k
             getattr(self, '_op_' + op['op'])(op)
+
+    def _softmax_stat_producers(self):
+        """{conv op index: slot} for the convolutions whose epilogue can emit the spatial-softmax partials of a
+        fusion operand (rtm3d_conv_desc.softmax_stat_slot): every operand of a fusion must be the whole 256-channel
+        output of a conv that takes the halo-tile kernel (stride 1, taps within +-1 pixel, 8x32 tiles cover the
+        iteration domain, kernel variant 2), otherwise the fusion keeps its own reduction pass."""
+        P = self.plan
+        slots = {}
+        for si, sop in enumerate(P.ops):
+            if sop['op'] != 'softmax':
+                continue
+            prods = []
+            for u in sop['us']:
+                cand = [k for k in range(si) if P.ops[k]['op'] == 'conv'
+                        and any(o is not None and o.tid == u.tid for o in P.ops[k]['out'])]
+                if not cand or u.coff != 0 or u.C != 256 or P.tensors[u.tid]['C'] != 256:
+                    prods = None
+                    break
+                prods.append(cand[-1])
+            if prods is None or len(set(prods)) != len(prods) or len(prods) > 3:
+                continue
+            ok = True
+            for k in prods:
+                op = P.ops[k]
+                G = op['groups']
+                M = P.B * op['Hm'] * op['Wm']
+                variant = op.get('variant')
+                if variant is None:
+                    variant = choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
+                ok = ok and variant == 2 and op['cout'] == 256 and G <= 4 and op['in_stride'] == 1 and not op['out_nchw']
+                ok = ok and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0 and len(op['taps'][0]) in (4, 9)
+                ok = ok and all(r is None for r in op['res']) and all(o.coff == 0 and o.C == 256 for o in op['out'])
+                ok = ok and all(abs(dy) <= 1 and abs(dx) <= 1 for tp in op['taps'] for dy, dx in tp)
+                ok = ok and P.tensors[op['inp'][0].tid]['pad'] >= 1 and op['cin'] % 64 == 0 and op['cin'] * len(op['taps'][0]) // 64 >= 4
+            if ok:
+                for i, k in enumerate(prods):
+                    slots[k] = i
+        return slots
 
     def _blob(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -487,6 +527,7 @@ class RealizedPlan(object):
             for t, (dy, dx) in enumerate(op['taps'][g]):
                 d.tap_dy[g][t], d.tap_dx[g][t] = dy, dx
         d.relu = 1 if op['relu'] else 0
+        d.softmax_stat_slot = self._stat_slots.get(self._k, -1)
         d.out_nchw_f32 = op['out_nchw']
         d.out_H, d.out_W = op['out_hw']
         M = self.plan.B * op['Hm'] * op['Wm']

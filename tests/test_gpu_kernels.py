@@ -187,6 +187,42 @@ def test_softmax_fuse_with_peaked_inputs():
     np.testing.assert_allclose(got, ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max())
 
 
+def test_softmax_fuse_with_epilogue_partials():
+    """Fusion whose three operands come from transposed convs on the halo-tile kernel: their epilogues emit the
+    spatial-softmax partials (softmax_stat_slot) and the fusion skips its reduction pass.  Checked against torch,
+    and the producers must really have been marked."""
+    B, H, W = 3, 8, 32
+    rng = np.random.default_rng(11)
+    P = plan_mod.Plan(B, H * 8, W * 8)
+    z0 = P.tensor(2 * H, 2 * W, 256, 0)
+    xs = [P.tensor(H, W, 256, 1) for _ in range(3)]
+    us = [P.tensor(2 * H, 2 * W, 256, 0) for _ in range(3)]
+    ws = [(rng.standard_normal((256, 256, 4, 4)) * sc / 32).astype(np.float32) for sc in (1.0, 2.5, 6.0)]
+    for x, u, w in zip(xs, us, ws):
+        P.deconv(x, u, w, name='up')
+        P.ops[-1]['variant'] = 2
+    z = P.tensor(2 * H, 2 * W, 256, 6)
+    P.softmax_fuse(z0, z, us, name='fuse')
+    zin = rng.standard_normal((B, 256, 2 * H, 2 * W)).astype(np.float32)
+    xin = [rng.standard_normal((B, 256, H, W)).astype(np.float32) for _ in range(3)]
+    R = plan_mod.RealizedPlan(P, 0)
+    assert sorted(R._stat_slots.values()) == [0, 1, 2]
+    for s_, arr in [(z0, zin)] + list(zip(xs, xin)):
+        _lib.check(R.lib.rtm3d_tensor_upload(R.ctx, R.tids[s_.tid], s_.coff, s_.C, np.ascontiguousarray(arr).ctypes.data_as(ctypes.c_void_p)))
+    dummy = torch.zeros(16, device='cuda'); outs = [torch.zeros(16, device='cuda') for _ in range(4)]
+    for _ in range(2):                                   # replay: the partial buffer is rewritten every forward
+        R.forward(torch.cuda.current_stream().cuda_stream, dummy.data_ptr(), [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    got = R.download(z)
+    R.close()
+    ref = h(torch.from_numpy(zin))
+    for x, w in zip(xin, ws):
+        t = h(F.conv_transpose2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), None, 2, 1))
+        ref = ref + t * torch.softmax(t.view(B, 256, -1), -1).view(B, 256, 2 * H, 2 * W)
+    ref = h(ref).numpy()
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3 * max(1.0, np.abs(ref).max()))
+
+
 def test_stem_and_headout_vs_torch():
     rng = np.random.default_rng(9)
     B, H, W = 2, 32, 64
