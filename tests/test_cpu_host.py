@@ -193,3 +193,20 @@ def test_kitti_label_lines(tmp_path):
     n = kr.write_kitti_label_file(str(tmp_path / 'data' / '000001.txt'), pl)
     assert n == 2 and len(open(str(tmp_path / 'data' / '000001.txt')).read().splitlines()) == 2
     assert kr.write_kitti_label_file(str(tmp_path / 'data' / '000002.txt'), None) == 0
+
+
+def test_float_estimate_division_is_exact_for_small_quotients():
+    """csrc/common.h div_small_q: q = int(float(m) * (1/d)), fixed up by +-1 from the remainder, is exact for
+    0 <= m < 2^31 whenever the quotient is below 2^21 (pixel -> image / row index).  Same arithmetic in numpy."""
+    rng = np.random.default_rng(5)
+    for d in (1, 2, 3, 7, 20, 80, 160, 320, 1280, 1920, 30720, 491520, 2 ** 20 + 1, 2 ** 24 + 3):
+        qmax = min(2 ** 21 - 1, (2 ** 31 - 1) // d)
+        q_true = np.concatenate([rng.integers(0, qmax + 1, 20000), [0, 1, qmax]]).astype(np.int64)
+        r_true = np.concatenate([rng.integers(0, d, 20000), [0, d - 1, d - 1]]).astype(np.int64)
+        m = q_true * d + r_true
+        m = m[m < 2 ** 31]
+        rcp = np.float32(1.0) / np.float32(d)
+        q = (m.astype(np.float32) * rcp).astype(np.int64)
+        r = m - q * d
+        q = q + (r >= d).astype(np.int64) - (r < 0).astype(np.int64)
+        np.testing.assert_array_equal(q, m // d)
