@@ -47,7 +47,9 @@ def parse_args():
     ap.add_argument('--height', type=int, default=384)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=10, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-full', action='store_true', help='whole BASELINE.md section-4 CPU protocol (adds minutes: one-thread bs=8)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the 3D-box L-inf check against the CPU oracle')
+    ap.add_argument('--parity-images', type=int, default=2)
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
@@ -55,25 +57,211 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(backbone, sd, H, W, n_images, cfg):
-    """The oracle timed on this host: forward + 2D decode (PyTorch-CPU fp32) and the SciPy 3D decode."""
+def _best_median(ts):
+    ts = sorted(ts)
+    return ts[0], ts[len(ts) // 2]
+
+
+def cpu_baseline(backbone, sd, H, W, cfg, full=False):
+    """The oracle timed on this host, BASELINE.md section 4: all host threads and one thread, bs=1 and bs=8,
+    1 warm-up + 3 timed runs (best / median), forward + 2D decode (images/s) and the SciPy 3D decode (objects/s)
+    separately.  Bounded by default (about 30-40 s): the one-thread leg runs bs=1 once warm + 2 timed and skips bs=8
+    unless --cpu-full.  `value` = whole path (forward + 2D + 3D decode of the detections found) at the best
+    all-thread configuration."""
     from oracle import rtm3d_ref, decode3d_ref
     from rtm3d_amd import weights
-    threads = torch.get_num_threads()
-    x = weights.synth_images(n_images, H, W, seed=1234)
+    nthreads = torch.get_num_threads()
+    th, tk = cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES
+    x8 = weights.synth_images(8, H, W, seed=1234)
     K = weights.synth_intrinsics()
-    rtm3d_ref.model_forward(x[:1], sd, backbone)            # warm-up (thread pool, oneDNN primitives)
-    t0 = time.time()
-    nobj = 0
-    for i in range(n_images):
-        dets, _ = rtm3d_ref.model_forward(x[i:i + 1], sd, backbone, cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES)
-        if dets[0][0] is not None:
-            nobj += len(dets[0][0])
-            decode3d_ref.optim_decode_bbox3d(dets[0][0].numpy(), dets[3][0].numpy(), K, cfg.DETECTOR.dim_ref, [0, -0.5, 20])
-    dt = time.time() - t0
-    return {'value': n_images / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d images bs=1 %s %dx%d fp32 PyTorch-CPU oracle forward + 2D decode + SciPy L-BFGS-B 3D decode of %d objects, %.1f s'
-                      % (n_images, backbone, H, W, nobj, dt)}
+    detail = {}
+
+    def time_forward(bs, runs, warm=1):
+        for _ in range(warm):
+            rtm3d_ref.model_forward(x8[:bs], sd, backbone, th, tk)
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            dets, _ = rtm3d_ref.model_forward(x8[:bs], sd, backbone, th, tk)
+            ts.append(time.perf_counter() - t0)
+        return ts, dets
+
+    dets8 = None
+    for bs in (1, 8):
+        ts, dets = time_forward(bs, 3)
+        best, med = _best_median(ts)
+        detail['forward+decode2d bs=%d threads=%d' % (bs, nthreads)] = {'best_s': best, 'median_s': med, 'images_per_s_best': bs / best}
+        if bs == 8:
+            dets8 = dets
+    torch.set_num_threads(1)
+    try:
+        ts, _ = time_forward(1, 3 if full else 2)
+        best, med = _best_median(ts)
+        detail['forward+decode2d bs=1 threads=1'] = {'best_s': best, 'median_s': med, 'images_per_s_best': 1 / best}
+        if full:
+            ts, _ = time_forward(8, 3)
+            best, med = _best_median(ts)
+            detail['forward+decode2d bs=8 threads=1'] = {'best_s': best, 'median_s': med, 'images_per_s_best': 8 / best}
+    finally:
+        torch.set_num_threads(nthreads)
+    # 3D decode: SciPy L-BFGS-B with Python-level objective/gradient, one thread by construction
+    objs = [(dets8[0][i].numpy(), dets8[3][i].numpy()) for i in range(8) if dets8[0][i] is not None]
+    nobj = sum(len(c) for c, _ in objs)
+    ts = []
+    for _ in range(3 if nobj else 0):
+        t0 = time.perf_counter()
+        cnt = 0
+        for c, v in objs:
+            decode3d_ref.optim_decode_bbox3d(c[:5], v[:5], K, cfg.DETECTOR.dim_ref, [0, -0.5, 20])
+            cnt += len(c[:5])
+        ts.append(time.perf_counter() - t0)
+    per_obj = None
+    if ts:
+        best, med = _best_median(ts)
+        per_obj = best / cnt
+        detail['decode3d scipy threads=1'] = {'objects': cnt, 'best_s': best, 'median_s': med, 'objects_per_s_best': cnt / best}
+    fw = max(detail['forward+decode2d bs=%d threads=%d' % (bs, nthreads)]['images_per_s_best'] for bs in (1, 8))
+    per_img = 1.0 / fw + (per_obj or 0.0) * nobj / 8.0
+    return {'value': 1.0 / per_img, 'unit': 'images/s', 'cores': nthreads, 'kind': 'port',
+            'sample': '%s %dx%d fp32 PyTorch-CPU oracle: forward+2D decode bs=1 and bs=8 (1 warm-up + 3 timed, best) on %d threads, '
+                      '+ SciPy L-BFGS-B 3D decode at %.1f objects/image (measured on %d objects, 3 runs, 1 thread); '
+                      'one-thread forward timed beside it' % (backbone, H, W, nthreads, nobj / 8.0, cnt if ts else 0),
+            'detail': detail}
+
+
+def parity_check(model, cfg, sd, backbone, H, W, k, dev, planted=12):
+    """BASELINE metric, second half: 3D-box L-inf of the device pipeline vs the CPU reference path (the oracle), on
+    the first k images of the benchmark workload.  Two regimes:
+      stage : the device decode kernels fed the ORACLE's fp32 logits, with `planted` exact cuboid projections per image
+              written over them (tests/golden/cases.plant_cuboids) so that real boxes are kept (fun < 0.1) next to the
+              workload's natural detections: indices must be identical, boxes are compared on the kept objects;
+      e2e   : images -> fp16 network -> device decode, against the fp32 oracle end to end: detections matched by
+              (class, y, x) cell, vertex / score L-inf on the matches, box L-inf on the objects BOTH sides keep."""
+    from oracle import rtm3d_ref, decode3d_ref
+    from rtm3d_amd import weights
+    from rtm3d_amd.model_utils import decode3d_slots
+    from tests.golden.cases import plant_cuboids
+    th, tk = float(cfg.DETECTOR.SCORE_THRESH), int(cfg.DETECTOR.TOPK_CANDIDATES)
+    dim_ref = cfg.DETECTOR.dim_ref
+    x = weights.synth_images(k, H, W, seed=1234)
+    K = weights.synth_intrinsics()
+    Kd = torch.as_tensor(np.tile(K, (k, 1)), dtype=torch.float64, device=dev)
+    dets_ref, logits_ref = rtm3d_ref.model_forward(x, sd, backbone, th, tk)
+
+    def box_params(xs):            # (n, 8) solver state -> (n, 7) [Ry, h, w, l, X, Y, Z]  (utils/model_utils.py:300-303)
+        return np.concatenate([np.arctan2(xs[:, 0:1], xs[:, 1:2]), xs[:, 3:5], xs[:, 2:3], xs[:, 5:8]], 1)
+
+    def angle_diff(a, b):
+        d = np.abs(a - b)
+        d[:, 0] = np.minimum(d[:, 0], 2 * np.pi - d[:, 0])
+        return d
+
+    def solve_ref(dets, b):
+        _, raw = decode3d_ref.optim_decode_bbox3d(dets[0][b].numpy(), dets[3][b].numpy(), K, dim_ref, [0, -0.5, 20], return_raw=True)
+        return raw
+
+    out = {'images': k, 'reference': 'oracle: PyTorch-CPU fp32 forward + Model.inference restatement + SciPy L-BFGS-B'}
+    # ---------------------------------------------------------------- stage regime (planted cuboids on oracle logits)
+    lg = [l.numpy().copy() for l in logits_ref]
+    truth = plant_cuboids(lg[0], lg[1:], K, planted, np.random.Generator(np.random.PCG64(2)))
+    raws_p = [None] * k
+    dets_p = rtm3d_ref.inference([torch.from_numpy(a) for a in lg], th, tk, 4.0)
+    det = model.decode2d([torch.from_numpy(a).to(dev) for a in lg])
+    boxes = decode3d_slots(det, Kd, dim_ref, [0, -0.5, 20])
+    torch.cuda.synchronize(dev)
+    n_dev = det.n.cpu().numpy()
+    xs, fs = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy()
+    st = {'objects': 0, 'index_mismatches': 0, 'kept_ref': 0, 'kept_dev': 0, 'keep_decision_mismatches': 0, 'box_linf': 0.0,
+          'vert_linf_px': 0.0}
+    for b in range(k):
+        nr = 0 if dets_p[0][b] is None else len(dets_p[0][b])
+        if nr:
+            raws_p[b] = solve_ref(dets_p, b)
+        if nr != int(n_dev[b]):
+            st['index_mismatches'] += abs(nr - int(n_dev[b]))
+            continue
+        if nr == 0:
+            continue
+        sl = slice(b * tk, b * tk + nr)
+        st['objects'] += nr
+        st['index_mismatches'] += int((det.cls[sl].cpu().numpy() != dets_p[0][b].numpy()).sum())
+        st['vert_linf_px'] = max(st['vert_linf_px'], float(np.abs(det.verts[sl].cpu().numpy() - dets_p[3][b].numpy()).max()))
+        raw = raws_p[b]
+        kr, kd = raw['kept'], fs[sl] < 0.1
+        st['kept_ref'] += int(kr.sum()); st['kept_dev'] += int(kd.sum())
+        st['keep_decision_mismatches'] += int((kr != kd).sum())
+        both = kr & kd
+        if both.any():
+            st['box_linf'] = max(st['box_linf'], float(angle_diff(box_params(xs[sl][both]), box_params(raw['x'][both])).max()))
+    out['stage'] = st
+    # ---------------------------------------------------------------- end to end (fp16 network on the device)
+    def match_e2e(det, boxes, dets_o, raws, only_cells=None):
+        """Device slots vs oracle detections, matched by (class, y, x) cell; only_cells restricts the oracle side."""
+        n_dev = det.n.cpu().numpy()
+        xs, fs = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy()
+        e = {'ref_detections': 0, 'dev_detections': int(n_dev.sum()), 'matched': 0, 'missed': 0, 'vert_linf_px': 0.0,
+             'score_linf': 0.0, 'kept_ref': 0, 'kept_dev': 0, 'kept_both': 0, 'box_linf': None, 'fun_rel_median': None}
+        frel = []
+        for b in range(k):
+            nd = int(n_dev[b])
+            sl = slice(b * tk, b * tk + nd)
+            cells = {}
+            if nd:
+                cl, mp, vv, sc = (t[sl].cpu().numpy() for t in (det.cls, det.mproj, det.verts, det.score))
+                for j, (c, m) in enumerate(zip(cl, mp)):
+                    cells[(int(c), int(m[0] // 4), int(m[1] // 4))] = j
+            if dets_o[0][b] is None:
+                continue
+            raw = raws[b]
+            for i, (c, m) in enumerate(zip(dets_o[0][b].numpy(), dets_o[2][b].numpy())):
+                cell = (int(c), int(m[0] // 4), int(m[1] // 4))
+                if only_cells is not None and (b,) + cell not in only_cells:
+                    continue
+                e['ref_detections'] += 1
+                e['kept_ref'] += int(raw['kept'][i])
+                j = cells.get(cell)
+                if j is None:
+                    e['missed'] += 1
+                    continue
+                e['matched'] += 1
+                e['kept_dev'] += int(fs[sl][j] < 0.1)
+                e['vert_linf_px'] = max(e['vert_linf_px'], float(np.abs(vv[j] - dets_o[3][b][i].numpy()).max()))
+                e['score_linf'] = max(e['score_linf'], abs(float(sc[j]) - float(dets_o[1][b][i])))
+                frel.append(abs(fs[sl][j] / raw['fun'][i] - 1.0))
+                if raw['kept'][i] and fs[sl][j] < 0.1:
+                    e['kept_both'] += 1
+                    d = float(angle_diff(box_params(xs[sl][j:j + 1]), box_params(raw['x'][i:i + 1])).max())
+                    e['box_linf'] = d if e['box_linf'] is None else max(e['box_linf'], d)
+        if frel:
+            e['fun_rel_median'] = float(np.median(frel))
+        return e
+
+    # (a) the workload's natural detections
+    xd = x.to(dev)
+    det, boxes, logits_dev = model.detect3d(xd, Kd)
+    torch.cuda.synchronize(dev)
+    raws_nat = [None if dets_ref[0][b] is None else solve_ref(dets_ref, b) for b in range(k)]
+    e_nat = match_e2e(det, boxes, dets_ref, raws_nat)
+    # (b) the same planted cuboids carried END TO END: the planting is applied to the device's own logits as the additive
+    # difference (planted - natural) of the oracle's, so each planted vertex on the device = exact projection + the fp16
+    # network's real error at that pixel; both sides then run their own 2D and 3D decode
+    lg_dev = [l + torch.from_numpy(p_ - n_.numpy()).to(dev) for l, p_, n_ in zip(logits_dev, lg, logits_ref)]
+    det2 = model.decode2d(lg_dev)
+    boxes2 = decode3d_slots(det2, Kd, dim_ref, [0, -0.5, 20])
+    torch.cuda.synchronize(dev)
+    only = set((b, c, xx, yy) for b in range(k) for (c, yy, xx, _, _, _) in truth[b])
+    e_pl = match_e2e(det2, boxes2, dets_p, raws_p, only)
+    out['e2e'] = e_nat
+    out['e2e_planted'] = e_pl
+    # the names VERDICT r01 asked for, flat
+    out.update({'stage_box_linf': st['box_linf'], 'e2e_vert_linf_px': max(e_nat['vert_linf_px'], e_pl['vert_linf_px']),
+                'e2e_box_linf': e_pl['box_linf'], 'matched': e_nat['matched'] + e_pl['matched'], 'missed': e_nat['missed'] + e_pl['missed']})
+    out['note'] = ('stage: device decode kernels on the oracle fp32 logits of the benchmark images with %d exact cuboid projections '
+                   'planted per image (bar: identical indices, boxes 1e-4).  e2e: fp16 network on the device vs the fp32 oracle end to '
+                   'end, detections matched by (class, y, x); the synthetic-weight workload itself has no cuboid-consistent key points '
+                   '(the reference keeps none), so box L-inf is measured on the same planted cuboids carried through the network '
+                   'additively (device logits + oracle(planted - natural)): planted vertices on the device = exact + real fp16 error' % planted)
+    return out
 
 
 def main():
@@ -194,9 +382,13 @@ def main():
                                                          i['bytes'] / i['ms'] / 1e6 if i['ms'] else 0), file=sys.stderr)
             print('forward total %.3f ms (per-op event timing)' % tot, file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, args.cpu_images, cfg)
+            out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, cfg, full=args.cpu_full)
         else:
             out['cpu_baseline'] = None
+        if not args.no_parity and world == 1:
+            out['parity'] = parity_check(model, cfg, sd, bb, H, W, args.parity_images, dev)
+        else:
+            out['parity'] = None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

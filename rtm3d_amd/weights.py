@@ -186,8 +186,10 @@ def _trained_gain(bkind, key):
     return g['conv']
 
 
-def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d'):
-    """Deterministic synthetic weights (fp32 CPU tensors) under the reference key names."""
+def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d', heat_gain=1.0):
+    """Deterministic synthetic weights (fp32 CPU tensors) under the reference key names.
+    ``heat_gain`` scales the last heat-map conv ("trained" style only): > 1 spreads the peak scores over a wider
+    range, as a trained detector's are, instead of the narrow band random features give."""
     assert style in ('init', 'trained')
     rng = np.random.Generator(np.random.PCG64(seed))
     bkind = parse_backbone(backbone)[0]
@@ -202,6 +204,8 @@ def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_var
             else:
                 a = math.sqrt(6.0 / fan_in) * _trained_gain(bkind, key)
             v = rng.uniform(-a, a, size=shape).astype(np.float32)
+            if style == 'trained' and heat_gain != 1.0 and key.endswith('main_kf_head.weight'):
+                v = v * np.float32(heat_gain)
         elif kind == 'conv_bias':
             if style == 'init':
                 bound = 1.0 / math.sqrt(256 * 9)

@@ -46,7 +46,13 @@ torch.set_num_threads(8)
 DIM_REF = [[1.52607842, 1.62858147, 3.88396124], [1.76067766, 0.6602296, 0.84220464],
            [1.73712792, 0.59677122, 1.76338868]]          # models/configs/rtm3d_dla34_kitti.yaml:18-27
 REF_LOC = [0, -0.5, 20]                                    # detect.py:74
-KFNS = {'DLA-34': ['level2', 'level3', 'level4', 'level5'], 'RESNET-18': ['layer1', 'layer2', 'layer3', 'layer4']}
+KFNS = {'DLA-34': ['level2', 'level3', 'level4', 'level5'], 'RESNET-18': ['layer1', 'layer2', 'layer3', 'layer4'],
+        'RESNET-34': ['layer1', 'layer2', 'layer3', 'layer4']}
+# The 2D-decode vectors are bit-exact pins of ATen's CPU sigmoid, whose rounding depends on the vector ISA the
+# generating host dispatches to (AVX-512: Sleef expf_u10 on 16-lane vectors with a scalar tail at n % 32, which is what
+# rtm3d_amd/csrc/decode2d.hip reproduces).  Regenerating on an AVX2-only box would silently change the expected bits.
+assert torch.backends.cpu.get_cpu_capability() == 'AVX512', \
+    'golden vectors must be generated on an AVX-512 host (got %s)' % torch.backends.cpu.get_cpu_capability()
 
 
 def make_cfg(backbone, thresh=0.4, topk=100):
@@ -88,18 +94,57 @@ def assert_tie_free(main_kf_logits, topk):
         assert len(torch.unique(s)) == len(s), 'tie among the top-(k+1) scores of image %d' % i
 
 
+OPTIONS = {'disp': None, 'maxcor': 10, 'ftol': 2.220446049250313e-09, 'gtol': 1e-05, 'eps': 1e-08,
+           'maxfun': 15000, 'maxiter': 15000, 'iprint': -1, 'maxls': 20, 'finite_diff_rel_step': None}   # utils/model_utils.py:290-291
+
+
+def decode3d_to_arrays(dets, K, prefix, out):
+    """Per image: the reference's optim_decode_bbox3d (kept boxes) AND the raw optimiser state (x, fun, nit) of
+    EVERY detection, kept or not, obtained by calling SciPy with the reference's own aimFun / jac."""
+    from oracle.decode3d_ref import COR
+    K33 = K.reshape(3, 3)
+    kept_total = 0
+    for b in range(len(dets[0])):
+        if dets[0][b] is None:
+            continue
+        clses, verts = dets[0][b].numpy(), dets[3][b].numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pl = ref_mu.optim_decode_bbox3d(clses, verts, K.copy(), DIM_REF, list(REF_LOC))
+            raw = {'x': [], 'fun': [], 'nit': []}
+            for cls, UV in zip(clses, verts):
+                dim = DIM_REF[cls]
+                X0 = np.array([0, 1] + [dim[2], dim[0], dim[1]] + REF_LOC)
+                res = minimize(ref_mu.aimFun(*(COR, K33, UV.T)), X0, method='L-BFGS-B',
+                               jac=ref_mu.jac(*(COR, K33, UV.T)), options=OPTIONS)
+                raw['x'].append(res.x); raw['fun'].append(res.fun); raw['nit'].append(res.nit)
+        out['%sclass_%d' % (prefix, b)] = np.array(pl.get_field('class'), np.int64)
+        out['%sRy_%d' % (prefix, b)] = np.asarray(pl.get_field('Ry'), np.float64)
+        out['%sdimension_%d' % (prefix, b)] = np.asarray(pl.get_field('dimension'), np.float64).reshape(-1, 3)
+        out['%slocation_%d' % (prefix, b)] = np.asarray(pl.get_field('location'), np.float64).reshape(-1, 3)
+        out['%sraw_x_%d' % (prefix, b)] = np.array(raw['x'])
+        out['%sraw_fun_%d' % (prefix, b)] = np.array(raw['fun'])
+        out['%sraw_nit_%d' % (prefix, b)] = np.array(raw['nit'])
+        kept_total += len(pl.get_field('class'))
+    return kept_total
+
+
+# (backbone, seed, heat_bias, heat_gain, B, H, W, tag): heat_gain/heat_bias chosen so that each image has ~20-30
+# detections whose scores spread over 0.4 .. 0.95 (random features alone give a narrow band of peak heights)
+E2E_CASES = [('DLA-34', 1, -16.9, 3.5, 2, 128, 256, 'small'), ('RESNET-18', 1, -22.8, 6.0, 2, 128, 256, 'small'),
+             ('RESNET-34', 1, -14.3, 4.0, 2, 128, 256, 'small'),
+             ('DLA-34', 1, -25.0, 4.5, 1, 384, 1280, 'full'), ('RESNET-18', 1, -30.0, 6.5, 1, 384, 1280, 'full')]
+
+
 def gen_e2e():
-    # (backbone, seed, heat_bias, B, H, W, tag)
-    cases = [('DLA-34', 1, -6.0, 2, 128, 256, 'small'), ('RESNET-18', 1, -5.0, 2, 128, 256, 'small'),
-             ('DLA-34', 1, -6.0, 1, 384, 1280, 'full'), ('RESNET-18', 1, -5.0, 1, 384, 1280, 'full')]
-    for bb, seed, hb, B, H, W, tag in cases:
-        sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
+    for bb, seed, hb, hg, B, H, W, tag in E2E_CASES:
+        sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb, heat_gain=hg)
         m = ref_model(bb, sd)
         x = weights.synth_images(B, H, W, seed=1234)
         with torch.no_grad():
             dets, logits = m(x)
         assert_tie_free(logits[0], 100)
-        out = {'backbone': bb, 'seed': seed, 'heat_bias': hb, 'style': 'trained', 'shape': np.array([B, H, W]),
+        out = {'backbone': bb, 'seed': seed, 'heat_bias': hb, 'heat_gain': hg, 'style': 'trained', 'shape': np.array([B, H, W]),
                'img_seed': 1234,
                # guards against drift of the numpy bit-stream that regenerates weights/images on another box
                'w_probe': sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1].copy(),
@@ -120,28 +165,50 @@ def gen_e2e():
                 out['offs_at_det_%d' % b] = logits[1][b][:, yi, xi].numpy()
                 out['moff_at_det_%d' % b] = logits[2][b][:, yi, xi].numpy()
         dets_to_arrays(dets, 'det_', out)
-        # 3D decode of image 0 through the reference function
         K = weights.synth_intrinsics()
-        if dets[0][0] is not None:
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                pl = ref_mu.optim_decode_bbox3d(dets[0][0].numpy(), dets[3][0].numpy(), K.copy(), DIM_REF, list(REF_LOC))
-            out['d3_class'] = np.array(pl.get_field('class'), np.int64)
-            out['d3_Ry'] = np.asarray(pl.get_field('Ry'), np.float64)
-            out['d3_dimension'] = np.asarray(pl.get_field('dimension'), np.float64)
-            out['d3_location'] = np.asarray(pl.get_field('location'), np.float64)
+        kept = decode3d_to_arrays(dets, K, 'd3_', out)
         out['K'] = K
         name = 'e2e_%s_%s.npz' % (bb.lower().replace('-', ''), tag)
         np.savez_compressed(os.path.join(HERE, name), **out)
-        print(name, 'ndet', out['det_n'], 'logit absmax', [float(l.abs().max()) for l in logits])
+        sc = [np.round(out['det_score_%d' % b][[0, -1]], 3) for b in range(B) if out['det_n'][b]]
+        print(name, 'ndet', out['det_n'], 'score range', sc, '3D kept', kept, 'logit absmax', [float(l.abs().max()) for l in logits])
 
 
-def gen_decode2d():
-    """Model.inference (models/model.py:29-75) on synthetic logits; weights are irrelevant here."""
+def gen_planted():
+    """Planted cuboids on reference-run logits (tests/golden/cases.py): the reference's own 2D decode + 3D decode,
+    which keeps the planted objects (fun < 0.1) and rejects the background's natural detections."""
+    gc = _load_cases()
+    m = ref_model('DLA-34', None)
+    for name, (fixture, _, nobj, _) in gc.PLANTED_CASES.items():
+        bg = np.load(os.path.join(HERE, fixture), allow_pickle=False)
+        th, tk, K, arrs, truth = gc.planted_inputs(name, bg)
+        lg = [torch.from_numpy(a) for a in arrs]
+        m.config.DETECTOR.SCORE_THRESH, m.config.DETECTOR.TOPK_CANDIDATES = th, tk
+        assert_tie_free(lg[0], tk)
+        with torch.no_grad():
+            dets = m.inference([l.clone() for l in lg])
+        out = {'probe': np.concatenate([a.reshape(-1)[:16] for a in arrs]), 'K': K, 'background': fixture}
+        dets_to_arrays(dets, 'det_', out)
+        kept = decode3d_to_arrays(dets, K, 'd3_', out)
+        for b in range(len(truth)):
+            kk = len(out['d3_class_%d' % b])
+            assert kk >= 10, 'image %d: the reference kept only %d planted boxes' % (b, kk)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        print(name, 'ndet', out['det_n'], 'kept by the reference', [len(out['d3_class_%d' % b]) for b in range(len(truth))],
+              'of', nobj, 'planted per image')
+
+
+def _load_cases():
     import importlib.util
     spec = importlib.util.spec_from_file_location('golden_cases', os.path.join(HERE, 'cases.py'))
     gc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gc)
+    return gc
+
+
+def gen_decode2d():
+    """Model.inference (models/model.py:29-75) on synthetic logits; weights are irrelevant here."""
+    gc = _load_cases()
     DECODE2D_CASES, decode2d_inputs = gc.DECODE2D_CASES, gc.decode2d_inputs
     m = ref_model('RESNET-18', None)
     out = {}
@@ -180,8 +247,7 @@ def gen_decode3d():
         warnings.simplefilter('ignore')
         pl = ref_mu.optim_decode_bbox3d(clses, uvs, K.copy(), DIM_REF, list(REF_LOC))
         raw = {'x': [], 'fun': [], 'nit': [], 'nfev': []}
-        options = {'disp': None, 'maxcor': 10, 'ftol': 2.220446049250313e-09, 'gtol': 1e-05, 'eps': 1e-08,
-                   'maxfun': 15000, 'maxiter': 15000, 'iprint': -1, 'maxls': 20, 'finite_diff_rel_step': None}
+        options = OPTIONS
         K33 = K.reshape(3, 3)
         for cls, UV in zip(clses, uvs):
             dim = DIM_REF[cls]
@@ -204,10 +270,12 @@ def gen_decode3d():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['e2e', 'decode2d', 'decode3d']
+    which = sys.argv[1:] or ['e2e', 'planted', 'decode2d', 'decode3d']
     if 'decode3d' in which:
         gen_decode3d()
     if 'decode2d' in which:
         gen_decode2d()
     if 'e2e' in which:
         gen_e2e()
+    if 'planted' in which:
+        gen_planted()

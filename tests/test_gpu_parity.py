@@ -15,10 +15,13 @@ pytestmark = pytest.mark.gpu
 from oracle import rtm3d_ref, decode3d_ref          # noqa: E402  (the checker)
 import rtm3d_amd                                     # noqa: E402
 from rtm3d_amd import weights, _lib                  # noqa: E402
-from tests.golden.cases import DECODE2D_CASES, decode2d_inputs   # noqa: E402
-from tests.util import load_golden, dets_from_golden, canon_dets, to_np   # noqa: E402
+from tests.golden.cases import DECODE2D_CASES, decode2d_inputs, PLANTED_CASES, planted_inputs   # noqa: E402
+from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_measurement   # noqa: E402
 
-LOGIT_RTOL = 0.03     # fp16 activations/weights, ~45 layers deep: |err| <= 0.03 * max(1, max|logit|)
+# fp16 activations/weights, fp32 accumulation, ~45 layers: |err| <= LOGIT_RTOL * max(1, max|ref|) per tensor.
+# = 2 x the largest error measured over every fixture / backbone / stage (profiles/r02_logit_error.json, tools/logit_error.py)
+LOGIT_RTOL = 0.004
+VERT_TOL_PX = 0.25    # vertices of matched detections: 16 regression channels x stride 4
 
 
 @pytest.fixture(scope='module')
@@ -140,42 +143,62 @@ def test_decode3d_random_vs_scipy(dev):
 
 
 # ------------------------------------------------------------------------------ network
-@pytest.mark.parametrize('fname', ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz'])
+def _rel_err(got, ref):
+    """max |got - ref| / max(1, max |ref|)"""
+    return float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
+
+
+E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
+
+
+@pytest.mark.parametrize('fname', E2E)
 def test_forward_logits_vs_reference_golden(dev, fname):
     g = load_golden(fname)
     bb = str(g['backbone'])
     B, H, W = [int(v) for v in g['shape']]
-    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']))
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
     x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
     m = make_model(bb, sd)
     (clses, scores, mprojs, verts, boxes), logits = m(x.to(dev))
     ref0 = g['logits_main_kf']
     tol = LOGIT_RTOL * max(1.0, np.abs(ref0).max())
-    np.testing.assert_allclose(logits[0].cpu().numpy(), ref0, rtol=0, atol=tol)
+    errs = {'main_kf': _rel_err(logits[0].cpu().numpy(), ref0)}
     for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
         if 'logits_' + name in g:
             ref = g['logits_' + name]; got = logits[i].cpu().numpy()
         else:
             ref = g['logits_%s_s4' % name]; got = logits[i][:, :, ::4, ::4].cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=0, atol=LOGIT_RTOL * max(1.0, np.abs(ref).max()))
-    # detections: every reference detection whose score is not within the fp16 error of the threshold
-    # must be found at the same (class, y, x), with vertices within 0.25 px (fp16 logits x stride 4)
+        errs[name] = _rel_err(got, ref)
+    record_measurement('logits_vs_reference_golden', fname, errs)
+    for name, e in errs.items():
+        assert e <= LOGIT_RTOL, (name, e)
+    # detections: every reference detection whose heat-map logit is further than the logit tolerance from the
+    # score threshold must be found at the same (class, y, x), with vertices within VERT_TOL_PX
+    thr_logit = float(np.log(0.4 / 0.6))
     n = g['det_n']
+    checked, vmax = 0, 0.0
     for b in range(B):
         if n[b] == 0:
             continue
         rc, rs, rm, rv, _ = dets_from_golden(g, 'det_', b)
+        margin = np.abs(np.log(rs.astype(np.float64) / (1.0 - rs.astype(np.float64))) - thr_logit)
+        sure = margin > 2 * tol
         if clses[b] is None:
-            assert (rs < 0.45).all()
+            assert not sure.any()
             continue
         got = {(int(c), int(mx // 4), int(my // 4)): v for c, (mx, my), v in
                zip(clses[b].cpu().numpy(), mprojs[b].cpu().numpy(), verts[b].cpu().numpy())}
-        for c, s, mp, v in zip(rc, rs, rm, rv):
-            if s < 0.45:
+        for c, s, mp, v, ok in zip(rc, rs, rm, rv, sure):
+            if not ok:
                 continue
             key = (int(c), int(mp[0] // 4), int(mp[1] // 4))
             assert key in got, (key, s)
-            assert np.abs(got[key] - v).max() < 0.25
+            vmax = max(vmax, float(np.abs(got[key] - v).max()))
+            checked += 1
+    record_measurement('e2e_detections_vs_reference_golden', fname, {'matched': checked, 'reference_detections': int(n.sum()),
+                                                                     'vertex_linf_px': vmax})
+    assert vmax < VERT_TOL_PX, vmax
+    assert checked >= 15 * B, checked       # the fixtures bite: ~20 detections per image with scores 0.4 .. 0.95
 
 
 @pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
@@ -187,35 +210,78 @@ def test_forward_stages_vs_oracle(dev, bb):
     logits = m.forward_logits(x.to(dev))
     _, lref, st = rtm3d_ref.model_forward(x, sd, bb, return_stages=True)
     plan = m._plan_for(3, 96, 160, dev)
+    errs = {}
     for i in range(4):
-        got = plan.download(plan.plan.named['feat%d' % i]); ref = st['feats'][i].numpy()
-        assert np.abs(got - ref).max() < LOGIT_RTOL * max(1.0, np.abs(ref).max())
-    got = plan.download(plan.plan.named['z']); ref = st['z'].numpy()
-    assert np.abs(got - ref).max() < LOGIT_RTOL * max(1.0, np.abs(ref).max())
-    for a, b in zip(logits, lref):
-        assert (a.cpu() - b).abs().max().item() < LOGIT_RTOL * max(1.0, b.abs().max().item())
+        errs['feat%d' % i] = _rel_err(plan.download(plan.plan.named['feat%d' % i]), st['feats'][i].numpy())
+    errs['z'] = _rel_err(plan.download(plan.plan.named['z']), st['z'].numpy())
+    for name, a, b in zip(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset'], logits, lref):
+        errs[name] = _rel_err(a.cpu().numpy(), b.numpy())
+    record_measurement('stages_vs_oracle', bb, errs)
+    for name, e in errs.items():
+        assert e <= LOGIT_RTOL, (name, e)
 
 
-def test_pipeline_on_oracle_logits_matches_reference_golden(dev):
-    """Stage parity regime (SURVEY H2 i): decode kernels fed the reference's fp32 logits reproduce the
-    reference's detections bit-exactly and its 3D boxes within 1e-4."""
-    g = load_golden('e2e_dla34_small.npz')
-    lg = [torch.from_numpy(g['logits_' + n]).to(dev) for n in ['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset']]
-    m = make_model('DLA-34')
+def _check_device_decode(dev, m, lg, g, K, topk=100):
+    """Reference logits in -> (1) the facade (Model.inference + optim_decode_bbox3d, detect.py:61-74) and (2) the
+    fused device path (decode2d -> decode3d_slots, no host hop) against the reference's detections (bit-exact),
+    its kept 3D boxes (identical set, <= 1e-4) and the raw optimiser state of every detection."""
+    dim_ref = rtm3d_amd.kitti_config().DETECTOR.dim_ref
+    B = len(g['det_n'])
     d = m.inference(lg)
-    for b in range(len(g['det_n'])):
-        if g['det_n'][b] == 0:
+    det = m.decode2d(lg)
+    Kd = torch.as_tensor(np.tile(K, (B, 1)), device=dev)
+    boxes = rtm3d_amd.model_utils.decode3d_slots(det, Kd, dim_ref, [0, -0.5, 20])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(det.n.cpu().numpy(), g['det_n'])
+    x, fun, st = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy(), boxes.status.cpu().numpy()
+    n_kept = 0
+    for b in range(B):
+        nb = int(g['det_n'][b])
+        assert (st[b * topk + nb:(b + 1) * topk] == -1).all()
+        if nb == 0:
             assert d[0][b] is None
             continue
         for k, r in enumerate(dets_from_golden(g, 'det_', b)):
             np.testing.assert_array_equal(to_np(d[k][b]), r)
-    if 'd3_class' in g:
-        out = rtm3d_amd.model_utils.optim_decode_bbox3d(to_np(d[0][0]), to_np(d[3][0]), g['K'], rtm3d_amd.kitti_config().DETECTOR.dim_ref, [0, -0.5, 20])
-        assert out.get_field('class') == g['d3_class'].tolist()
-        if len(g['d3_class']):
-            np.testing.assert_allclose(out.get_field('location'), g['d3_location'], atol=1e-4)
-            np.testing.assert_allclose(out.get_field('dimension'), g['d3_dimension'], atol=1e-4)
-            np.testing.assert_allclose(out.get_field('Ry'), g['d3_Ry'], atol=1e-4)
+        np.testing.assert_array_equal(det.verts[b * topk:b * topk + nb].cpu().numpy(), g['det_verts_%d' % b])
+        # (1) drop-in call of detect.py:71-74
+        out = rtm3d_amd.model_utils.optim_decode_bbox3d(to_np(d[0][b]), to_np(d[3][b]), K, dim_ref, [0, -0.5, 20])
+        assert out.get_field('class') == g['d3_class_%d' % b].tolist()
+        np.testing.assert_allclose(out.get_field('location').reshape(-1, 3), g['d3_location_%d' % b], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out.get_field('dimension').reshape(-1, 3), g['d3_dimension_%d' % b], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out.get_field('Ry'), g['d3_Ry_%d' % b], rtol=0, atol=1e-4)
+        # (2) device slots: same keep/reject decision for every detection; kept objects within 1e-4 of the reference's
+        # optimum; rejected ones (non-cuboid key points, fun >> 0.1, flat valleys) end at the same objective value
+        xs, fs = x[b * topk:b * topk + nb], fun[b * topk:b * topk + nb]
+        rx, rf = g['d3_raw_x_%d' % b], g['d3_raw_fun_%d' % b]
+        kept = rf < 0.1
+        np.testing.assert_array_equal(fs < 0.1, kept)
+        np.testing.assert_allclose(xs[kept], rx[kept], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(fs, rf, rtol=1e-2, atol=1e-6)
+        n_kept += int(kept.sum())
+    return n_kept
+
+
+@pytest.mark.parametrize('fname', ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz'])
+def test_pipeline_on_oracle_logits_matches_reference_golden(dev, fname):
+    """Stage parity regime (SURVEY H2 i): decode kernels fed the reference's fp32 logits reproduce the reference's
+    detections bit-exactly and the solver state of every detection (these natural detections are not cuboid
+    projections: the reference rejects all of them, and so must the device)."""
+    g = load_golden(fname)
+    lg = [torch.from_numpy(g['logits_' + n]).to(dev) for n in ['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset']]
+    _check_device_decode(dev, make_model('DLA-34'), lg, g, g['K'])
+
+
+@pytest.mark.parametrize('name', sorted(PLANTED_CASES))
+def test_planted_boxes_decode2d_to_decode3d_vs_reference(dev, name):
+    """Hand-off decode2d -> decode3d on objects the REFERENCE keeps: cuboid projections planted into reference-run
+    logits (tests/golden/cases.py); >= 10 kept boxes per image next to rejected natural detections."""
+    g = load_golden(name + '.npz')
+    th, tk, K, arrs, _ = planted_inputs(name, load_golden(PLANTED_CASES[name][0]))
+    np.testing.assert_array_equal(np.concatenate([a.reshape(-1)[:16] for a in arrs]), g['probe'])
+    lg = [torch.from_numpy(a).to(dev) for a in arrs]
+    n_kept = _check_device_decode(dev, make_model('DLA-34', None, th, tk), lg, g, K, tk)
+    assert n_kept >= 10 * len(g['det_n'])
 
 
 def test_detect3d_pipeline_and_batch_invariance(dev):

@@ -7,10 +7,10 @@ import torch
 
 from oracle import rtm3d_ref, decode3d_ref
 from rtm3d_amd import weights
-from tests.golden.cases import DECODE2D_CASES, decode2d_inputs
+from tests.golden.cases import DECODE2D_CASES, decode2d_inputs, PLANTED_CASES, planted_inputs, DIM_REF
 from tests.util import load_golden, dets_from_golden, to_np, canon_dets
 
-E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
+E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
 
 
 @pytest.mark.parametrize('fname', E2E)
@@ -18,7 +18,7 @@ def test_oracle_forward_matches_reference(fname):
     g = load_golden(fname)
     bb = str(g['backbone'])
     B, H, W = [int(v) for v in g['shape']]
-    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']))
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
     x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
     # the seeded generators must reproduce the tensors the reference was run on
     np.testing.assert_array_equal(sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1], g['w_probe'])
@@ -43,6 +43,37 @@ def test_oracle_forward_matches_reference(fname):
         np.testing.assert_allclose(dets[1][b].numpy(), ref[1], atol=1e-5)
         for k in (2, 3, 4):
             np.testing.assert_allclose(dets[k][b].numpy(), ref[k], atol=2e-4)
+    # 3D decode of image 0's reference detections: every detection's raw optimiser state, kept or not
+    if n[0]:
+        ref = dets_from_golden(g, 'det_', 0)
+        _check_decode3d(g, 0, ref[0], ref[3], g['K'])
+
+
+def _check_decode3d(g, b, clses, verts, K):
+    res, raw = decode3d_ref.optim_decode_bbox3d(clses, verts, K, DIM_REF, [0, -0.5, 20], return_raw=True)
+    np.testing.assert_array_equal(np.array(res['class'], np.int64), g['d3_class_%d' % b])
+    np.testing.assert_array_equal(raw['nit'], g['d3_raw_nit_%d' % b])
+    np.testing.assert_allclose(raw['x'], g['d3_raw_x_%d' % b], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(raw['fun'], g['d3_raw_fun_%d' % b], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(res['location'], g['d3_location_%d' % b], atol=1e-9)
+    np.testing.assert_allclose(res['dimension'], g['d3_dimension_%d' % b], atol=1e-9)
+    np.testing.assert_allclose(res['Ry'], g['d3_Ry_%d' % b], atol=1e-9)
+
+
+@pytest.mark.parametrize('name', sorted(PLANTED_CASES))
+def test_oracle_planted_pipeline_matches_reference(name):
+    """Planted cuboids on reference-run logits: the oracle's 2D decode is bit-exact and its 3D decode keeps exactly
+    the objects the reference kept (>= 10 per image), with the same boxes."""
+    g = load_golden(name + '.npz')
+    th, tk, K, arrs, truth = planted_inputs(name, load_golden(PLANTED_CASES[name][0]))
+    np.testing.assert_array_equal(np.concatenate([a.reshape(-1)[:16] for a in arrs]), g['probe'])
+    dets = rtm3d_ref.inference([torch.from_numpy(a) for a in arrs], th, tk, 4.0)
+    for b in range(len(g['det_n'])):
+        got = [to_np(d[b]) for d in dets]
+        for a, r in zip(got, dets_from_golden(g, 'det_', b)):
+            np.testing.assert_array_equal(a, r)
+        assert len(g['d3_class_%d' % b]) >= 10 and (g['d3_raw_fun_%d' % b] >= 0.1).any()     # kept AND rejected objects
+        _check_decode3d(g, b, got[0], got[3], K)
 
 
 @pytest.mark.parametrize('name', DECODE2D_CASES)

@@ -24,3 +24,24 @@ def dets_from_golden(g, prefix, b):
 
 def to_np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+# ---- measured-error log: the GPU parity tests record what they measured (not only pass/fail); the file is copied to
+# profiles/ by hand after a GPU run (gpurun_out/ is the only directory that travels back from the GPU box)
+_MEASURED = {}
+
+
+def record_measurement(group, key, value):
+    import atexit
+    import json
+    if not _MEASURED:
+        def dump():
+            out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+            try:
+                os.makedirs(out, exist_ok=True)
+                with open(os.path.join(out, 'measured_errors.json'), 'w') as f:
+                    json.dump(_MEASURED, f, indent=1, sort_keys=True)
+            except OSError:
+                pass
+        atexit.register(dump)
+    _MEASURED.setdefault(group, {})[key] = value
