@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 2
+#define RTM3D_ABI_VERSION 3
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -162,6 +162,17 @@ int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_ver
 int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
                          const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
                          const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
+
+/* Fixed-size detection records for collecting the results of a sharded batch (new functionality: the reference's
+ * inference is single-GPU, detect.py:18): slot (image, rank) -> 32 fp32 =
+ *   [0] class  [1] score  [2:4] main key point  [4:20] 8 vertices (x, y)  [20:24] 2D box
+ *   [24:27] dimension (h, w, l)  [27:30] location  [30] Ry = atan2(x0, x1)    (the ParamList fields of
+ *   utils/model_utils.py:300-303, rounded to fp32)   [31] flag: 0 empty, 1 2D only, 2 3D kept (fun < fun_accept, :298).
+ * Slots with rank >= d_n[image] are written as 32 zeros.  d_x/d_fun/d_status (solver outputs of
+ * rtm3d_decode3d_slots) may all be NULL: fields 24..30 are then zero and the flag is 0/1.  d_rec: B*topk*32 floats. */
+int rtm3d_pack_records(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls, const float* d_score,
+                       const float* d_mproj, const float* d_verts, const float* d_bbox, const double* d_x,
+                       const double* d_fun, const int32_t* d_status, double fun_accept, float* d_rec);
 
 /* "smoke" head-table variant (its source is not in the reference snapshot: PARITY
  * UNPINNED, published SMOKE formulation): closed-form box from the 8 regression channels at each key

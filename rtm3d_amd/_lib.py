@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_GROUPS, MAX_TAPS = 4, 49
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -59,6 +59,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_decode3d': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
+    'rtm3d_pack_records': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_double, c_void_p]),
     'rtm3d_decode_smoke': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_preprocess': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

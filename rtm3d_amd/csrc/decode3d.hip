@@ -125,3 +125,52 @@ extern "C" int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, 
     if (e != hipSuccess) { rt_set_error("decode3d_scalar launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Detection records for the multi-GPU all-gather: one 32-float record per (image, rank) slot, see
+// rtm3d_amd/distributed.py for the layout.  One thread per float: stores are fully coalesced, the loads are a
+// few scattered dwords per slot.  Arithmetic = the field definitions of utils/model_utils.py:300-303 (Ry = atan2,
+// dimension = (h, w, l) = x[3], x[4], x[2], location = x[5:8]) rounded to fp32; empty slots are all zero.
+__global__ __launch_bounds__(256) void pack_records_kernel(int total, int topk, const int32_t* __restrict__ n,
+                                                          const int64_t* __restrict__ cls, const float* __restrict__ score,
+                                                          const float* __restrict__ mproj, const float* __restrict__ verts,
+                                                          const float* __restrict__ bbox, const double* __restrict__ x,
+                                                          const double* __restrict__ fun, const int32_t* __restrict__ status,
+                                                          double fun_accept, float* __restrict__ rec) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int slot = t >> 5, f = t & 31;
+    const int img = slot / topk;
+    float v = 0.0f;
+    if (slot - img * topk < n[img]) {
+        const bool kept = x && status[slot] >= 0 && fun[slot] < fun_accept;
+        if (f == 0) v = (float)cls[slot];
+        else if (f == 1) v = score[slot];
+        else if (f < 4) v = mproj[(size_t)slot * 2 + (f - 2)];
+        else if (f < 20) v = verts[(size_t)slot * 16 + (f - 4)];
+        else if (f < 24) v = bbox[(size_t)slot * 4 + (f - 20)];
+        else if (f == 31) v = kept ? 2.0f : 1.0f;
+        else if (x) {
+            const double* xs = x + (size_t)slot * 8;
+            if (f < 27) v = (float)xs[f == 26 ? 2 : f - 21];           // (h, w, l) = x[3], x[4], x[2]
+            else if (f < 30) v = (float)xs[f - 22];                    // X, Y, Z = x[5..7]
+            else v = (float)atan2(xs[0], xs[1]);
+        }
+    }
+    rec[t] = v;
+}
+
+extern "C" int rtm3d_pack_records(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls, const float* d_score,
+                                  const float* d_mproj, const float* d_verts, const float* d_bbox, const double* d_x,
+                                  const double* d_fun, const int32_t* d_status, double fun_accept, float* d_rec) {
+    if (B <= 0 || topk <= 0) { rt_set_error("pack_records: bad sizes"); return 1; }
+    if (!d_n || !d_cls || !d_score || !d_mproj || !d_verts || !d_bbox || !d_rec || (d_x && (!d_fun || !d_status))) {
+        rt_set_error("pack_records: null pointer"); return 1;
+    }
+    const int total = B * topk * 32;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, total, topk, d_n, d_cls,
+                       d_score, d_mproj, d_verts, d_bbox, d_x, d_fun, d_status, fun_accept, d_rec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("pack_records launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}

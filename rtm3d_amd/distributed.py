@@ -14,40 +14,69 @@ RECORD = 32
 
 
 def shard_range(total, rank, world):
-    """Contiguous split [lo, hi) of `total` images for `rank`; the first total % world ranks get one more."""
+    """Contiguous split [lo, hi) of `total` images for `rank`; the first total % world ranks get one more.
+    Shards may differ by one image: for the fixed-batch pipeline / the all-gather use ``padded_shard``."""
     base, extra = divmod(total, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def pack_records(n, cls, score, mproj, verts, bbox, topk, boxes=None):
-    """(B,) counts + (B*topk, ...) slot tensors -> (B, topk, 32) fp32 records (device-side torch ops)."""
+def pack_records(n, cls, score, mproj, verts, bbox, topk, boxes=None, out=None):
+    """(B,) counts + (B*topk, ...) slot tensors (+ the solver's Boxes3D) -> (B, topk, 32) fp32 records, written by ONE
+    HIP launch on the current stream (rtm3d_pack_records; no ATen kernels between the 2D decode and the collective).
+    Device tensors only: there is no CPU path."""
+    import ctypes
+    from . import _lib
+    from .model_utils import FUN_ACCEPT
+    if not n.is_cuda:
+        raise RuntimeError('rtm3d_amd.distributed.pack_records needs CUDA (ROCm) tensors; there is no CPU path')
     B = n.shape[0]
-    rec = torch.zeros(B, topk, RECORD, dtype=torch.float32, device=n.device)
-    valid = torch.arange(topk, device=n.device)[None, :] < n[:, None].to(torch.int64)
-    rec[..., 0] = cls.view(B, topk).to(torch.float32)
-    rec[..., 1] = score.view(B, topk)
-    rec[..., 2:4] = mproj.view(B, topk, 2)
-    rec[..., 4:20] = verts.view(B, topk, 16)
-    rec[..., 20:24] = bbox.view(B, topk, 4)
-    flag = valid.to(torch.float32)
-    if boxes is not None:
-        kept = boxes.kept.view(B, topk) & valid
-        rec[..., 24:27] = boxes.dimension.view(B, topk, 3).to(torch.float32)
-        rec[..., 27:30] = boxes.location.view(B, topk, 3).to(torch.float32)
-        rec[..., 30] = boxes.Ry.view(B, topk).to(torch.float32)
-        flag = flag + kept.to(torch.float32)
-    rec[..., 31] = flag
-    return rec * (flag > 0).to(torch.float32)[..., None]
+    dev = n.device
+    if cls.shape[0] != B * topk:
+        raise ValueError('pack_records: %d slots for %d images x topk %d' % (cls.shape[0], B, topk))
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty(B, topk, RECORD, dtype=torch.float32, device=dev)
+        x, fun, st = (boxes.x.data_ptr(), boxes.fun.data_ptr(), boxes.status.data_ptr()) if boxes is not None else (0, 0, 0)
+        _lib.check(lib.rtm3d_pack_records(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, int(topk), n.data_ptr(),
+                                          cls.data_ptr(), score.data_ptr(), mproj.data_ptr(), verts.data_ptr(), bbox.data_ptr(),
+                                          x, fun, st, float(FUN_ACCEPT), out.data_ptr()), 'pack_records')
+    return out
 
 
-def all_gather_records(rec, group=None):
+def padded_shard(total, rank, world):
+    """Equal-size shards for the fixed-shape pipeline and the all-gather: every rank processes ``per = ceil(total/world)``
+    image slots [lo, lo+per); the slots at or beyond ``total`` are padding (feed any image, e.g. a repeat of the last
+    one) and are dropped by ``trim_gathered``.  Returns (lo, hi_valid, per)."""
+    per = -(-total // world)
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total), per
+
+
+def trim_gathered(rec, total):
+    """Drop the padding slots of ``padded_shard`` from a gathered (world*per, topk, 32) record tensor."""
+    return rec[:total]
+
+
+def all_gather_records(rec, group=None, check_shapes=False, always=False):
     """(b, topk, 32) per rank -> (world*b, topk, 32) ordered by global image index.  One collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return rec
     world = dist.get_world_size(group)
+    rec = rec.contiguous()
+    if check_shapes:
+        # a one-off guard for new callers (not for the per-step path): uneven shards would make the collective write
+        # out of step; all ranks must hand in the same (b, topk, 32)
+        shp = torch.tensor(list(rec.shape), dtype=torch.int64, device=rec.device)
+        lo, hi = shp.clone(), shp.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            raise ValueError('all_gather_records: shard shapes differ across ranks (%s..%s); pad with padded_shard()'
+                             % (lo.tolist(), hi.tolist()))
     out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    dist.all_gather_into_tensor(out, rec, group=group)
     return out
 
 

@@ -179,6 +179,10 @@ class Model(object):
         with torch.cuda.device(dev):
             if out is None:
                 out = Detections(B, topk, dev)
+            elif out.n.shape[0] != B or out.topk != topk or out.cls.shape[0] != B * topk:
+                # the kernel writes B*topk slots: a smaller buffer would be overrun, a larger one would keep stale rows
+                raise ValueError('decode2d: output slots are for %d images x top-%d, the logits hold %d images and topk is %d'
+                                 % (out.n.shape[0], out.topk, B, topk))
             key = ('d2', B, K, H, W, dev.index)
             ws = self._ws.get(key)
             if ws is None:

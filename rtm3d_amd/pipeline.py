@@ -39,6 +39,11 @@ class Detect3DPipeline(object):
             self.boxes = [Boxes3D(batch * self.topk, self.dev) for _ in range(depth)]
             self.ev_a = [torch.cuda.Event() for _ in range(depth)]
             self.ev_b = [torch.cuda.Event() for _ in range(depth)]
+            self.rec_local = [torch.zeros(batch, self.topk, rdist.RECORD, dtype=torch.float32, device=self.dev) for _ in range(depth)]
+            # optional event pair around the collective (bench diagnostics; timing events are not free, so off by default)
+            self.time_gather = False
+            self.ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
+            self.ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
         self.rec = [None] * depth
         self.count = 0
 
@@ -57,6 +62,14 @@ class Detect3DPipeline(object):
 
     def submit(self, x, K_per_image):
         """Enqueue one batch; returns its step index.  Asynchronous."""
+        if x.dim() != 4 or x.shape[0] != self.B:
+            # the slots are preallocated for `batch` images: a larger shard would write out of bounds on the device, a
+            # smaller one would leave the previous step's detections in the unused rows (pad the last shard instead:
+            # rtm3d_amd.distributed.padded_shard)
+            raise ValueError('Detect3DPipeline was built for batches of %d images, got input of shape %s'
+                             % (self.B, tuple(x.shape)))
+        if not isinstance(K_per_image, torch.Tensor) or K_per_image.numel() != self.B * 9 or not K_per_image.is_cuda:
+            raise ValueError('K_per_image must be a CUDA tensor with %d x 9 intrinsics' % self.B)
         i = self.count
         s = i % self.depth
         main = torch.cuda.current_stream(self.dev)
@@ -70,8 +83,13 @@ class Detect3DPipeline(object):
             if self.decode3d:
                 decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
             d = self.det[s]
-            rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk, self.boxes[s])
-            self.rec[s] = rdist.all_gather_records(rec) if self.gather else rec
+            rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk,
+                                     self.boxes[s] if self.decode3d else None, out=self.rec_local[s])
+            if self.time_gather:
+                self.ev_g0[s].record(self.side)
+            self.rec[s] = rdist.all_gather_records(rec, always=self.gather == 'always') if self.gather else rec
+            if self.time_gather:
+                self.ev_g1[s].record(self.side)
             self.ev_b[s].record(self.side)
         self.count += 1
         return i
@@ -81,6 +99,12 @@ class Detect3DPipeline(object):
         s = i % self.depth
         torch.cuda.current_stream(self.dev).wait_event(self.ev_b[s])
         return self.rec[s]
+
+    def gather_us(self, i):
+        """Device time of step i's collective in microseconds (needs time_gather = True before the step; waits for it)."""
+        s = i % self.depth
+        self.ev_g1[s].synchronize()
+        return self.ev_g0[s].elapsed_time(self.ev_g1[s]) * 1e3
 
     def drain(self):
         self.side.synchronize()

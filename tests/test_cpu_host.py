@@ -133,8 +133,9 @@ def _gloo_worker(rank, world, port, q):
     cls = torch.randint(0, 3, (b * topk,), generator=gen)
     score = torch.rand(b * topk, generator=gen); mproj = torch.rand(b * topk, 2, generator=gen)
     verts = torch.rand(b * topk, 8, 2, generator=gen); bbox = torch.rand(b * topk, 4, generator=gen)
-    rec = rdist.pack_records(n, cls, score, mproj, verts, bbox, topk)
-    allrec = rdist.all_gather_records(rec)
+    from tests.util import pack_records_reference
+    rec = pack_records_reference(n, cls, score, mproj, verts, bbox, topk)      # CPU tensors: the product packer is HIP-only
+    allrec = rdist.all_gather_records(rec, check_shapes=True)
     assert allrec.shape == (world * b, topk, rdist.RECORD)
     assert torch.equal(allrec[lo:hi], rec)
     un = rdist.unpack_records(allrec[lo:hi])
@@ -157,6 +158,62 @@ def test_all_gather_records_gloo_world2():
         assert p.exitcode == 0
     res = dict(q.get() for _ in range(2))
     assert res[0] == res[1]           # every rank holds the same gathered batch
+
+
+def _gloo_uneven_worker(rank, world, port, q):
+    """10 images over 3 ranks: padded equal shards (4, 4, 2 + 2 padding), gathered, trimmed, unpacked."""
+    import torch.distributed as dist
+    from tests.util import pack_records_reference
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    total, topk = 10, 4
+    lo, hi, per = rdist.padded_shard(total, rank, world)
+    assert per == 4 and hi - lo == (4, 4, 2)[rank]
+    # global, rank-independent synthetic detections: image g has (g % 5) objects of class g % 3
+    def image(gidx):
+        gen = torch.Generator().manual_seed(1000 + gidx)
+        return gidx % 5, torch.full((topk,), gidx % 3, dtype=torch.int64), torch.rand(topk, generator=gen)
+    n, cls, score = [], [], []
+    for slot in range(per):
+        gidx = lo + slot
+        cnt, c, sc = image(min(gidx, total - 1))            # padding slots repeat the last image
+        n.append(cnt); cls.append(c); score.append(sc)
+    n = torch.tensor(n, dtype=torch.int32); cls = torch.cat(cls); score = torch.cat(score)
+    z2, z16, z4 = torch.zeros(per * topk, 2), torch.zeros(per * topk, 8, 2), torch.zeros(per * topk, 4)
+    rec = pack_records_reference(n, cls, score, z2, z16, z4, topk)
+    allrec = rdist.trim_gathered(rdist.all_gather_records(rec, check_shapes=True), total)
+    assert allrec.shape == (total, topk, rdist.RECORD)
+    un = rdist.unpack_records(allrec)
+    for gidx in range(total):
+        cnt, c, sc = image(gidx)
+        if cnt == 0:
+            assert un[gidx] is None
+        else:
+            assert len(un[gidx]['cls']) == cnt and torch.equal(un[gidx]['cls'], c[:cnt]) and torch.equal(un[gidx]['score'], sc[:cnt])
+    # uneven shapes handed to the collective are caught by the guard, on every rank
+    bad = rec[: per - (1 if rank == 2 else 0)]
+    try:
+        rdist.all_gather_records(bad, check_shapes=True)
+        ok = False
+    except ValueError:
+        ok = True
+    q.put((rank, ok, float(allrec.sum())))
+    dist.destroy_process_group()
+
+
+def test_all_gather_records_gloo_world3_uneven_shards():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    ps = [ctx.Process(target=_gloo_uneven_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(180)
+        assert p.exitcode == 0
+    res = [q.get() for _ in range(3)]
+    assert all(ok for _, ok, _ in res) and len(set(s for _, _, s in res)) == 1
 
 
 def test_box_projection_matches_reference_golden_vectors():

@@ -16,11 +16,14 @@ from oracle import rtm3d_ref, decode3d_ref          # noqa: E402  (the checker)
 import rtm3d_amd                                     # noqa: E402
 from rtm3d_amd import weights, _lib                  # noqa: E402
 from tests.golden.cases import DECODE2D_CASES, decode2d_inputs, PLANTED_CASES, planted_inputs   # noqa: E402
-from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_measurement   # noqa: E402
+from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_measurement, pack_records_reference   # noqa: E402
 
-# fp16 activations/weights, fp32 accumulation, ~45 layers: |err| <= LOGIT_RTOL * max(1, max|ref|) per tensor.
-# = 2 x the largest error measured over every fixture / backbone / stage (profiles/r02_logit_error.json, tools/logit_error.py)
-LOGIT_RTOL = 0.004
+# fp16 activations/weights, fp32 accumulation, ~45 layers: |err| <= tol * max(1, max|ref|) per tensor, tol = 2 x the
+# largest error MEASURED on the MI355X over every fixture / backbone for that stage (profiles/r02_logit_error.json, written
+# by these tests through tests/util.record_measurement): logits 0.0042, fused map z 0.0063, backbone features 0.0014.
+LOGIT_RTOL = 0.0085
+Z_RTOL = 0.013
+FEAT_RTOL = 0.003
 VERT_TOL_PX = 0.25    # vertices of matched detections: 16 regression channels x stride 4
 
 
@@ -218,7 +221,7 @@ def test_forward_stages_vs_oracle(dev, bb):
         errs[name] = _rel_err(a.cpu().numpy(), b.numpy())
     record_measurement('stages_vs_oracle', bb, errs)
     for name, e in errs.items():
-        assert e <= LOGIT_RTOL, (name, e)
+        assert e <= (FEAT_RTOL if name.startswith('feat') else Z_RTOL if name == 'z' else LOGIT_RTOL), (name, e)
 
 
 def _check_device_decode(dev, m, lg, g, K, topk=100):
@@ -473,8 +476,72 @@ def test_two_stream_pipeline_equals_serial_path(dev):
     pipe.drain()
     for i, x in enumerate(xs):
         det, boxes, _ = m.detect3d(x, K)
-        ref = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, 100, boxes)
+        ref = pack_records_reference(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, 100, boxes)
         torch.cuda.synchronize()
         assert torch.equal(got[i], ref), i
     recs = rdist.unpack_records(got[0])
     assert len(recs) == B and all(r is None or r['verts'].shape[1:] == (8, 2) for r in recs)
+
+
+def test_pack_records_hip_equals_reference(dev):
+    """rtm3d_pack_records (one HIP launch) against the plain-torch definition of the record: every field incl. the fp64
+    atan2, the kept flag at the fun < 0.1 edge and the zeroing of empty slots."""
+    from rtm3d_amd import distributed as rdist
+    from rtm3d_amd.model_utils import Boxes3D
+    g = torch.Generator().manual_seed(5)
+    B, topk = 5, 100
+    n = torch.tensor([0, 100, 37, 1, 64], dtype=torch.int32)
+    cls = torch.randint(0, 3, (B * topk,), generator=g)
+    score = torch.rand(B * topk, generator=g); mproj = torch.rand(B * topk, 2, generator=g) * 1280
+    verts = (torch.rand(B * topk, 8, 2, generator=g) - 0.3) * 1500; bbox = torch.rand(B * topk, 4, generator=g) * 1280
+    boxes = Boxes3D(B * topk, dev)
+    boxes.x.copy_((torch.randn(B * topk, 8, generator=g, dtype=torch.float64) * 10).to(dev))
+    fun = torch.rand(B * topk, generator=g, dtype=torch.float64) * 0.2
+    fun[100] = 0.1; fun[101] = float(np.nextafter(0.1, 0.0)); fun[102] = float('inf')
+    boxes.fun.copy_(fun.to(dev))
+    boxes.status.copy_(torch.randint(-1, 3, (B * topk,), generator=g).to(torch.int32).to(dev))
+    t = [a.to(dev) for a in (n, cls, score, mproj, verts, bbox)]
+    for bx in (boxes, None):
+        got = rdist.pack_records(*t, topk, bx)
+        ref = pack_records_reference(*t, topk, bx)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        assert bx is None or int((got[..., 31] == 2).sum()) > 0
+    with pytest.raises(RuntimeError):
+        rdist.pack_records(n, cls, score, mproj, verts, bbox, topk)          # CPU tensors: no CPU path
+
+
+def test_pipeline_rejects_wrong_batch(dev):
+    """a shard larger than the preallocated slots would be an out-of-bounds device write, a smaller one
+    would leave stale detections in the unused rows - both must raise before anything is launched."""
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    from rtm3d_amd.model import Detections
+    bb = 'RESNET-18'
+    m = make_model(bb, weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5))
+    pipe = Detect3DPipeline(m, 3, dev, gather=False)
+    K3 = torch.as_tensor(np.tile(weights.synth_intrinsics(), (3, 1)), device=dev)
+    for nb in (2, 4):
+        with pytest.raises(ValueError):
+            pipe.submit(torch.zeros(nb, 3, 64, 128, device=dev), K3)
+    with pytest.raises(ValueError):
+        pipe.submit(torch.zeros(3, 3, 64, 128, device=dev), K3[:2])
+    lg = [torch.zeros(2, c, 16, 32, device=dev) for c in (3, 16, 2, 2)]
+    with pytest.raises(ValueError):
+        m.decode2d(lg, out=Detections(3, 100, dev))
+    with pytest.raises(ValueError):
+        m.decode2d(lg, out=Detections(2, 50, dev))
+    assert pipe.submit(torch.zeros(3, 3, 64, 128, device=dev), K3) == 0
+    pipe.drain()
+
+
+def test_pipeline_under_nccl_world1(dev):
+    """Multi-GPU readiness on a one-GPU box: Detect3DPipeline with the record all-gather forced through RCCL (backend
+    "nccl", world size 1) on the side stream, event-ordered against the main stream, equals the serial path."""
+    import subprocess, sys, os
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    port = str(29600 + os.getpid() % 300)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'nccl_world1_worker.py'), port], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'nccl world-1 pipeline ok' in r.stdout

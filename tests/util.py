@@ -26,6 +26,28 @@ def to_np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
+def pack_records_reference(n, cls, score, mproj, verts, bbox, topk, boxes=None):
+    """Plain-torch definition of the 32-float detection record (rtm3d_amd/distributed.py layout): the checker of the
+    HIP kernel rtm3d_pack_records, and the record builder of the CPU (gloo) tests."""
+    B = n.shape[0]
+    rec = torch.zeros(B, topk, 32, dtype=torch.float32, device=n.device)
+    valid = torch.arange(topk, device=n.device)[None, :] < n[:, None].to(torch.int64)
+    rec[..., 0] = cls.view(B, topk).to(torch.float32)
+    rec[..., 1] = score.view(B, topk)
+    rec[..., 2:4] = mproj.view(B, topk, 2)
+    rec[..., 4:20] = verts.view(B, topk, 16)
+    rec[..., 20:24] = bbox.view(B, topk, 4)
+    flag = valid.to(torch.float32)
+    if boxes is not None:
+        kept = boxes.kept.view(B, topk) & valid
+        rec[..., 24:27] = boxes.dimension.view(B, topk, 3).to(torch.float32)
+        rec[..., 27:30] = boxes.location.view(B, topk, 3).to(torch.float32)
+        rec[..., 30] = boxes.Ry.view(B, topk).to(torch.float32)
+        flag = flag + kept.to(torch.float32)
+    rec[..., 31] = flag
+    return torch.where((flag > 0)[..., None], rec, torch.zeros_like(rec))
+
+
 # ---- measured-error log: the GPU parity tests record what they measured (not only pass/fail); the file is copied to
 # profiles/ by hand after a GPU run (gpurun_out/ is the only directory that travels back from the GPU box)
 _MEASURED = {}
