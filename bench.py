@@ -273,7 +273,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # under torchrun (RANK set) the process group is created even for one rank, so that the collective path of the
+    # N > 1 runs (RCCL all-gather on the side stream + the diagnostics below) can be rehearsed on a one-GPU box
+    use_dist = world > 1 or 'RANK' in os.environ
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=dev)
     if args.gpus != world and rank == 0:
@@ -294,7 +297,9 @@ def main():
     topk = int(cfg.DETECTOR.TOPK_CANDIDATES)
 
     from rtm3d_amd.pipeline import Detect3DPipeline
-    pipe = Detect3DPipeline(model, B, dev, gather=True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus) if not args.serial else None
+    pipe = Detect3DPipeline(model, B, dev, gather='always' if use_dist else True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus) if not args.serial else None
+    if pipe is not None and use_dist:
+        pipe.time_gather = True                 # event pair around the collective on the side stream (diagnostics)
 
     def step():
         if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
@@ -302,7 +307,7 @@ def main():
             return i, pipe.det[i % pipe.depth]
         det, boxes, _ = model.detect3d(x, K)
         rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, topk, boxes)
-        return rdist.all_gather_records(rec), det
+        return rdist.all_gather_records(rec, always=use_dist), det
 
     # ---- warm-up (also records the plan) and choice of the dominant kernel for the live probe
     rec, det = step()
@@ -322,7 +327,7 @@ def main():
         if pipe is not None:
             pipe.drain()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -332,14 +337,33 @@ def main():
         rec, det = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    last_step = rec
+    multi = None
+    if use_dist:
+        # diagnostics for the scaling run (outside the timed region): every rank's own wall time, the device time of the
+        # last all-gather, and how many ranks' record blocks arrived intact in rank 0's gathered batch
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        multi = {'per_rank_ms_per_step': [round(v / args.steps * 1e3, 3) for v in allt.tolist()]}
     dom_ms, dom_n = plan.probe_read()
     n_det = det.n.sum().item()
     if pipe is not None:
         rec = pipe.results(rec)
+    if use_dist:
+        torch.cuda.synchronize(dev)
+        local = pipe.rec_local[last_step % pipe.depth] if pipe is not None else rec[rank * B:(rank + 1) * B]
+        cs = local.double().sum().reshape(1)
+        allcs = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allcs, cs)
+        blocks = rec.view(world, -1).double().sum(1)
+        multi['ranks_seen'] = int((blocks == allcs).sum().item()) if rec.shape[0] == world * B else 0
+        multi['gathered_shape'] = list(rec.shape)
+        multi['allgather_us_last_step'] = round(pipe.gather_us(last_step), 1) if pipe is not None else None
+        multi['allgather_bytes_per_rank'] = int(local.numel() * 4)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -371,7 +395,7 @@ def main():
                                       % (bb.lower().replace('-', ''), B, H, W),
                           'global_batch': B * world, 'parallelism': 'dp%d' % world,
                           'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9},
-               'roofline': roof}
+               'roofline': roof, 'multi_gpu': multi}
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'
         if args.per_op:
@@ -390,7 +414,7 @@ def main():
         else:
             out['parity'] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -81,8 +81,8 @@ typedef struct rtm3d_conv_desc {
     int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
     int relu;
     int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
-    int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 1 = direct dot2 (small cin),
-                                              2 = MFMA 256x256 tile (cout % 256 == 0), 3 = register-direct MFMA (cin 4/16/32) */
+    int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 2 = MFMA 256x256 tile
+                                              (cout % 256 == 0), 3 = register-direct MFMA (cin 4/16/32); 1 is retired */
     int bn_tile;                           /* MFMA: cout tile the weights were packed for (16/32/64/128) */
     int out_nchw_f32;                      /* 0, or 1..4 = index+1 into rtm3d_forward's out_logits[] */
     int out_H, out_W;                      /* only for out_nchw_f32 */
@@ -113,6 +113,12 @@ int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_u, const in
 /* Replay the plan.  d_in: fp32 NCHW (B,3,H,W) normalised image batch (detect.py:53);
  * d_out_logits[4]: fp32 NCHW (B,3|16|2|2,H/4,W/4) = pred_logits of models/model.py:22-27.        */
 int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]);
+
+/* enable != 0: rtm3d_forward replays the plan as ONE hipGraph launch instead of ~60 kernel launches (small batches are
+ * launch-gap bound; the reference's detect.py runs bs = 1).  The graph is captured on first use per distinct
+ * (d_in, d_out_logits[0..3]) pointer tuple - kernel arguments are baked into it - and up to 8 tuples are cached (LRU).
+ * Results are bit-identical to the eager replay.  The live probe (rtm3d_probe_set) forces the eager path.            */
+int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable);
 
 /* Per-op timing of one replay with hipEvents (synchronous; for profiling/bench):
  * h_ms[i] = elapsed ms of op i; returns number of ops through *n_ops (h_ms may be NULL).          */

@@ -105,7 +105,5 @@ bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);
 bool conv_smallc_supported(int cin, int cout, int ntaps);
 hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s);
-hipError_t launch_conv_direct(const ConvKArgs& a, int ksize, int groups, hipStream_t s);
-bool conv_direct_supported(int cin, int cout, int ntaps);
 hipError_t launch_maxpool(const PoolKArgs& a, hipStream_t s);
 hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s);

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_DIRECT, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -57,6 +57,12 @@ struct rtm3d_ctx {
     int probe_op = -1;
     std::vector<hipEvent_t> probe_ev;   // 2 * PROBE_RING events
     int probe_count = 0;
+    // hipGraph replay (rtm3d_ctx_set_graph): one instantiated graph per distinct (input, 4 x output) pointer tuple
+    int graph_mode = 0;
+    hipStream_t capture_stream = nullptr;
+    struct GraphEntry { const void* key[5]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0;
 };
 static const int PROBE_RING = 64;
 
@@ -66,6 +72,15 @@ extern "C" int rtm3d_abi_version(void) { return RTM3D_ABI_VERSION; }
 extern "C" int rtm3d_ctx_create(int device, rtm3d_ctx** out) {
     if (!out) RT_FAIL("ctx_create: null out");
     RT_HIP(hipSetDevice(device));
+    // The persistent convolution kernels deal workgroup b to XCD b & 7 and size their grids as CUs / 8 per XCD
+    // (conv_mfma256.hip): they are written for the 8-XCD, 256-CU SPX partition of an MI355X.  Another partition
+    // mode would still compute correctly (tickets are per counter, not per physical XCD) but the L2 locality the
+    // tile order is built for would be gone, so it is refused instead of silently running slow.
+    int xccs = 0, cus = 0;
+    RT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) xccs = 0;
+    if ((xccs != 0 && xccs != 8) || cus < 8 || (cus % 8) != 0)
+        RT_FAIL("ctx_create: device %d reports %d XCCs / %d CUs; librtm3d_hip is built for the 8-XCD (SPX) MI355X", device, xccs, cus);
     rtm3d_ctx* c = new rtm3d_ctx();
     c->device = device;
     *out = c;
@@ -78,6 +93,8 @@ extern "C" void rtm3d_ctx_destroy(rtm3d_ctx* ctx) {
     for (auto p : ctx->blobs) (void)hipFree(p);
     for (auto p : ctx->extra) (void)hipFree(p);
     for (auto e : ctx->probe_ev) (void)hipEventDestroy(e);
+    for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
+    if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
     delete ctx;
 }
 
@@ -254,13 +271,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         op.kind = OP_CONV_SMALLC;
         op.name = d->cin == 4 ? "stem7x7_regmfma" : "conv_smallc_regmfma";
     } else {
-        if (d->groups != 1 || d->out_nchw_f32) RT_FAIL("op_conv(direct): groups/NCHW output unsupported");
-        if (!conv_direct_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(direct): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
-        if (wbytes != (size_t)d->ntaps * d->cin * d->cout * sizeof(f16)) RT_FAIL("op_conv(direct): weight blob size mismatch");
-        if (bbytes != (size_t)d->cout * sizeof(float)) RT_FAIL("op_conv(direct): bias blob size mismatch");
-        a.g[0].w_off = 0; a.g[0].bias_off = 0;
-        op.kind = OP_CONV_DIRECT;
-        op.name = "conv_direct_dot2";
+        RT_FAIL("op_conv: unknown kernel %d (0 = MFMA 128-px tile, 2 = MFMA 256x256 tile, 3 = register-direct MFMA)", d->kernel);
     }
     if (d->softmax_stat_slot >= 0 && stat_slot < 0) RT_FAIL("op_conv: softmax_stat_slot needs kernel = 2");
     if (stat_slot >= 0) {
@@ -386,7 +397,9 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
     ctx->extra.push_back(st);
     a.stats = (float*)st;
     op.flops = 0;
-    op.bytes = 2.0 * a.B * a.H * a.W * 256.0 * (2.0 * n_u + 2.0);
+    // apply pass: read z_in and every u once, write z_out; the stand-alone reduction pass (when the producers did not
+    // emit the partials from their epilogues) reads every u once more
+    op.bytes = 2.0 * a.B * a.H * a.W * 256.0 * ((emitted ? 1.0 : 2.0) * n_u + 2.0);
     ctx->ops.push_back(op);
     return 0;
 }
@@ -409,7 +422,6 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
             e = launch_conv_headout(a, s);
             break;
         }
-        case OP_CONV_DIRECT: e = launch_conv_direct(op.conv, 0, op.groups, s); break;
         case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
         case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;
     }
@@ -417,18 +429,66 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
     return 0;
 }
 
+static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4], bool probes) {
+    // The persistent convs share 8 self-resetting ticket counters; after an aborted launch (or a replay torn down half
+    // way) they would be left non-zero and later launches would silently skip tiles.  Zeroing them in stream order at
+    // the head of every replay costs one 32-byte memset node.
+    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, 8 * sizeof(unsigned int), s));
+    const int n = (int)ctx->ops.size();
+    for (int i = 0; i < n; ++i) {
+        const bool probe = probes && (i == ctx->probe_op);
+        const int slot = ctx->probe_count % PROBE_RING;
+        if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], s));
+        if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) return 1;
+        if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], s)); ctx->probe_count++; }
+    }
+    return 0;
+}
+
+static const size_t GRAPH_CACHE = 8;
+
 extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
     if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward: null argument");
     if (!d_out_logits[0]) RT_FAIL("forward: null logits buffer 0");
     if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
-    const int n = (int)ctx->ops.size();
-    for (int i = 0; i < n; ++i) {
-        const bool probe = (i == ctx->probe_op);
-        const int slot = ctx->probe_count % PROBE_RING;
-        if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], (hipStream_t)stream));
-        if (launch_op(ctx, ctx->ops[i], (hipStream_t)stream, d_in, d_out_logits)) return 1;
-        if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], (hipStream_t)stream)); ctx->probe_count++; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->graph_mode || ctx->probe_op >= 0) return replay_eager(ctx, s, d_in, d_out_logits, true);
+    // graph replay: the kernel arguments are baked into the graph, so it is keyed by the caller's buffers (a serving
+    // loop re-uses the same few buffers: torch's caching allocator hands back the same blocks)
+    const void* key[5] = {d_in, d_out_logits[0], d_out_logits[1], d_out_logits[2], d_out_logits[3]};
+    ctx->graph_clock++;
+    for (auto& ge : ctx->graphs)
+        if (!memcmp(ge.key, key, sizeof(key))) { ge.last_use = ctx->graph_clock; ctx->graph_hits++; RT_HIP(hipGraphLaunch(ge.exec, s)); return 0; }
+    // a caller that hands over fresh buffers every time would pay a capture per call: give up on graphs for this context
+    if (++ctx->graph_captures > 32 && ctx->graph_hits < ctx->graph_captures) { ctx->graph_mode = 0; return replay_eager(ctx, s, d_in, d_out_logits, true); }
+    // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured)
+    if (!ctx->capture_stream) RT_HIP(hipStreamCreateWithFlags(&ctx->capture_stream, hipStreamNonBlocking));
+    RT_HIP(hipStreamBeginCapture(ctx->capture_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = replay_eager(ctx, ctx->capture_stream, d_in, d_out_logits, false);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(ctx->capture_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+    if (ec != hipSuccess) { rt_set_error("forward: graph capture failed: %s", hipGetErrorString(ec)); return 1; }
+    rtm3d_ctx::GraphEntry ge;
+    memcpy(ge.key, key, sizeof(key));
+    ge.graph = graph;
+    RT_HIP(hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+    ge.last_use = ctx->graph_clock;
+    if (ctx->graphs.size() >= GRAPH_CACHE) {            // evict the least recently used entry
+        size_t lru = 0;
+        for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+        (void)hipGraphExecDestroy(ctx->graphs[lru].exec); (void)hipGraphDestroy(ctx->graphs[lru].graph);
+        ctx->graphs[lru] = ge;
+    } else {
+        ctx->graphs.push_back(ge);
     }
+    RT_HIP(hipGraphLaunch(ge.exec, s));
+    return 0;
+}
+
+extern "C" int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable) {
+    if (!ctx) RT_FAIL("ctx_set_graph: null context");
+    ctx->graph_mode = enable ? 1 : 0;
     return 0;
 }
 
@@ -468,6 +528,7 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) RT_HIP(hipEventCreate(&e));
     hipStream_t s = (hipStream_t)stream;
+    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, 8 * sizeof(unsigned int), s));
     RT_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < n; ++i) {
         if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) return 1;

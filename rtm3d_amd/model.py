@@ -21,6 +21,10 @@ from . import plan as plan_mod
 from .weights import parse_backbone, state_dict_spec, synth_state_dict, head_table
 
 
+GRAPH_MAX_BATCH = 8
+MAX_PLANS = 3
+
+
 class _Namespace(object):
     """Place-holder for the sub-module attributes the reference exposes (model.backbone, ...)."""
     def __init__(self, owner, prefix):
@@ -58,8 +62,9 @@ class Model(object):
         self.training = True                     # nn.Module default; detect.py:31 calls eval()
         self.export = False
         self._device = None
-        self._plans = {}
+        self._plans = OrderedDict()
         self._ws = {}
+        self.use_graph = None                    # None: automatic (hipGraph replay for batches <= GRAPH_MAX_BATCH)
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
         self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant)
         self.backbone = _Namespace(self, 'backbone')
@@ -90,7 +95,7 @@ class Model(object):
     def _drop_plans(self):
         for p in self._plans.values():
             p.close()
-        self._plans = {}
+        self._plans = OrderedDict()
 
     def eval(self):
         self.training = False
@@ -127,10 +132,21 @@ class Model(object):
     def _plan_for(self, B, H, W, device):
         key = (B, H, W, device.index)
         p = self._plans.get(key)
+        if p is not None:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
         if p is None:
+            # a plan owns its activation workspace (about 9 GB at bs=32) and a packed copy of the weights: keep the
+            # MAX_PLANS most recently used shapes (a trailing partial batch, or the reference DatasetReader's
+            # rectangular mode, otherwise keeps adding contexts until hipMalloc fails) and free the rest
+            while len(self._plans) >= MAX_PLANS:
+                old = next(iter(self._plans))
+                self._plans.pop(old).close()
             ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
+                # small batches are bound by launch gaps, not by the kernels: replay those plans as one hipGraph
+                use_graph = self.use_graph if self.use_graph is not None else B <= GRAPH_MAX_BATCH
+                p.set_graph(use_graph)
             self._plans[key] = p
         return p
 

@@ -362,9 +362,12 @@ def choose_bn_tile(cout, M):
 
 def choose_variant(cin, cout, M, groups, out_nchw):
     """2 = 256x256-tile 8-wave kernel (conv_mfma256.hip) when the layer has enough tiles to fill the
-    chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 1 = direct (small cin)."""
+    chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 3 = register-direct MFMA kernel for the
+    4/16/32-channel layers of the stems (conv_smallc.hip)."""
     if cin % 64:
-        return 3 if cin in (4, 16, 32) else 1
+        if cin not in (4, 16, 32):
+            raise NotImplementedError('no HIP kernel for a convolution with %d input channels (supported: 4, 16, 32, multiples of 64)' % cin)
+        return 3
     if not out_nchw and cout % 256 == 0:
         # one persistent workgroup per CU (256 CUs): at least two full rounds.  (A single nearly full round -
         # DLA level4, 240 tiles - is 0.1 ms faster per forward on its own but 0.4 ms slower per pipelined
@@ -438,13 +441,6 @@ def pack_headout_weights(ws, biases):
         out[h, :, :, :, :co, :] = wt.transpose(4, 1, 2, 0, 3)
         bias[h, :co] = b
     return np.ascontiguousarray(out).astype(np.float16).reshape(-1), bias.reshape(-1)
-
-
-def pack_direct_weights(wt):
-    """wt: (taps, cout, cin) -> fp16 [tap][cin/2][cout][2]."""
-    taps, cout, cin = wt.shape
-    w = wt.transpose(0, 2, 1).reshape(taps, cin // 2, 2, cout).transpose(0, 1, 3, 2)
-    return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
 
 
 class RealizedPlan(object):
@@ -555,9 +551,7 @@ class RealizedPlan(object):
             d.kernel, d.bn_tile = 0, bn
             d.w_blob, d.bias_blob = self._blob(np.concatenate(packed)), self._blob(np.concatenate(biases))
         else:
-            assert G == 1
-            d.kernel, d.bn_tile = 1, 0
-            d.w_blob, d.bias_blob = self._blob(pack_direct_weights(op['w'][0])), self._blob(op['bias'][0])
+            raise NotImplementedError('no HIP kernel for conv %s (cin=%d)' % (op['name'], op['cin']))
         _lib.check(self.lib.rtm3d_op_conv(self.ctx, ctypes.byref(d)), 'op_conv ' + op['name'])
 
     def _op_headout(self, op):
@@ -594,6 +588,10 @@ class RealizedPlan(object):
             _lib.check(self.lib.rtm3d_op_info(self.ctx, i, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(nm)), 'op_info')
             info.append({'kernel': nm.value.decode(), 'name': self.plan.ops[i]['name'], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
         return info
+
+    def set_graph(self, enable):
+        """Replay the plan as one hipGraph launch (bit-identical results; see rtm3d_ctx_set_graph)."""
+        _lib.check(self.lib.rtm3d_ctx_set_graph(self.ctx, 1 if enable else 0), 'ctx_set_graph')
 
     def probe_set(self, op_index):
         _lib.check(self.lib.rtm3d_probe_set(self.ctx, int(op_index)), 'probe_set')

@@ -49,7 +49,6 @@ CONV_CASES = [
     (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
     (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
     (1, 9, 13, 32, 64, 1, 1, 1, False, False, 3, 0),        # smallc 1x1
-    (2, 16, 24, 16, 16, 3, 1, 1, True, True, 1, 0),         # direct dot2 kernel (kept as a variant), residual
 ]
 
 

