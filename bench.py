@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
+    ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
 
@@ -288,6 +289,8 @@ def main():
     B, H, W = args.batch, args.height, args.width
     cfg = rtm3d_amd.kitti_config(bb)
     seed, hb = SYNTH.get(bb, (1, -6.0))
+    if args.heat_bias is not None:
+        hb = args.heat_bias
     sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
     model = rtm3d_amd.create_model(cfg).to(dev).eval()
     model.load_state_dict(sd)
@@ -398,6 +401,8 @@ def main():
                'roofline': roof, 'multi_gpu': multi}
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'
+        if args.heat_bias is not None:
+            out['DIAGNOSTIC'] = 'heat-map bias overridden to %g (not the benchmark workload)' % args.heat_bias
         if args.per_op:
             tot = sum(i['ms'] for i in info)
             print('%-28s %-22s %9s %9s %8s' % ('op', 'kernel', 'ms', 'TFLOP/s', 'GB/s'), file=sys.stderr)

@@ -110,7 +110,8 @@ int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor,
  * (models/nets/keypoint_fpn_fusion.py:60-69).  n_u <= 3.                                         */
 int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_u, const int* u_tensors);
 
-/* Replay the plan.  d_in: fp32 NCHW (B,3,H,W) normalised image batch (detect.py:53);
+/* Replay the plan.  d_in: fp32 NCHW (B,3,H,W) normalised image batch (detect.py:53), or NULL when the input tensor was
+ * filled by rtm3d_preprocess_batch (out_mode 1);
  * d_out_logits[4]: fp32 NCHW (B,3|16|2|2,H/4,W/4) = pred_logits of models/model.py:22-27.        */
 int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]);
 
@@ -194,6 +195,26 @@ int rtm3d_decode_smoke(void* stream, int B, int topk, const int32_t* d_n, const 
  * float32((v/255. - mean[c]) / std[c]) computed in float64 like the reference; d_sums3: 3 x uint64 scratch. */
 int rtm3d_preprocess(void* stream, const uint8_t* d_img_hwc, int h, int w, float* d_out_chw, int H, int W,
                      const float* d_lut, unsigned long long* d_sums3);
+
+/* The same step for a whole batch of ragged images in TWO launches (interior + per-image channel sums, then borders),
+ * with the bilinear Resize of the reference's TestTransform in front (preprocess/transforms.py:480-495,
+ * cv2.resize INTER_LINEAR: OpenCV's published 11-bit fixed-point algorithm restated - OpenCV is an un-vendored
+ * dependency absent from this image, so the resize itself is PARITY UNPINNED; equal source and target sizes are the
+ * identity and then the result is bit-identical to rtm3d_preprocess).
+ *   h_imgs[B]: HOST array of DEVICE pointers to uint8 HWC images; h_hw[2B] = (h, w) per image;
+ *   h_resized_hw[2B] = (h', w') after Resize, or NULL for "already resized";
+ *   out_mode 0: d_out = fp32 NCHW (B,3,H,W), the reference's `imgs` (detect.py:53);
+ *   out_mode 1: d_out = the network's own operand, fp16 NHWC4 [B][H+2*out_border][W+2*out_border][4] (4th channel 0;
+ *               the border itself is not written) - see rtm3d_input_tensor / rtm3d_forward with d_in == NULL;
+ *   d_lut fp32 [3][256] as above, d_lut16 the same table rounded to fp16 (mode 1), d_sums: B*3 uint64 scratch. */
+int rtm3d_preprocess_batch(void* stream, int B, const uint8_t* const* h_imgs, const int* h_hw, const int* h_resized_hw,
+                           void* d_out, int out_mode, int H, int W, int out_border, const float* d_lut, const void* d_lut16,
+                           unsigned long long* d_sums);
+
+/* Device address and geometry of the plan's 4-channel fp16 input tensor (written by rtm3d_op_input_nhwc4 from the caller's
+ * fp32 batch, or directly by rtm3d_preprocess_batch in out_mode 1, after which rtm3d_forward is called with d_in == NULL
+ * and skips the conversion).  Fails if the plan has no such tensor.                                                  */
+int rtm3d_input_tensor(rtm3d_ctx* ctx, void** d_base, int* B, int* H, int* W, int* border);
 
 /* Stream restricted to `n_cus` compute units (hipExtStreamCreateWithCUMask) for the latency-bound
  * 3D decode of the two-stream pipeline; destroy with rtm3d_stream_destroy.                          */

@@ -65,6 +65,10 @@ SIGNATURES = {
     'rtm3d_decode_smoke': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_preprocess': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rtm3d_preprocess_batch': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p]),
+    'rtm3d_input_tensor': (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_stream_create_cumask': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
     'rtm3d_stream_destroy': (c_int, [c_void_p]),
     'rtm3d_decode3d_scalar': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -59,3 +59,161 @@ extern "C" int rtm3d_preprocess(void* stream, const uint8_t* d_img_hwc, int h, i
     if (e != hipSuccess) { rt_set_error("preprocess launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Batched form: B ragged uint8 HWC images -> Resize (preprocess/transforms.py:480-495) -> mean-colour letterbox
+// (datasets/dataset_reader.py:175-195) -> Normalize/ToTensor (transforms.py:110-120, 312-317) in TWO launches for the
+// whole batch (interior + channel sums, then borders), writing either the reference's fp32 NCHW batch or directly the
+// network's own operand: the 4-channel padded NHWC fp16 tensor the stem reads (no fp32 round trip through HBM).
+//
+// Resize = cv2.resize(..., INTER_LINEAR) on 8-bit data, restated from OpenCV's published algorithm (imgproc
+// resize.cpp, 8UC3 path; OpenCV is a third-party dependency absent from /root/reference AND from this image, the
+// reference pins no version - PARITY UNPINNED for this step):
+//   fx = (float)((dx + 0.5) * (double)(src_w / dst_w) - 0.5); sx = floor(fx); fx -= sx; clamped at both ends (fx = 0);
+//   coefficients a0 = round_half_even((1 - fx) * 2048), a1 = round_half_even(fx * 2048) as int16 (same for rows);
+//   horizontal pass in int32: r = S[sx] * a0 + S[sx + 1] * a1; vertical pass + rounding:
+//   dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// With equal source and destination sizes this is the identity (OpenCV returns a copy), so the no-resize case is
+// bit-identical to rtm3d_preprocess above.
+#define PRE_MAX_BATCH 64
+struct PreBatch {
+    const uint8_t* img[PRE_MAX_BATCH];
+    int h[PRE_MAX_BATCH], w[PRE_MAX_BATCH];       // source size
+    int rh[PRE_MAX_BATCH], rw[PRE_MAX_BATCH];     // size after Resize (== source size: no resize)
+};
+
+__device__ __forceinline__ void resize_coef(int d, double scale, int ssize, int& s0, int& s1, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
+    s0 = si;
+    s1 = si + 1 < ssize ? si + 1 : ssize - 1;
+    c0 = (int)rintf((1.f - f) * 2048.f);
+    c1 = (int)rintf(f * 2048.f);
+}
+
+__device__ __forceinline__ unsigned int resized_pixel(const uint8_t* __restrict__ img, int w, int c, int y0, int y1, int b0, int b1,
+                                                      int x0, int x1, int a0, int a1) {
+    const int r0 = (int)img[((size_t)y0 * w + x0) * 3 + c] * a0 + (int)img[((size_t)y0 * w + x1) * 3 + c] * a1;
+    const int r1 = (int)img[((size_t)y1 * w + x0) * 3 + c] * a0 + (int)img[((size_t)y1 * w + x1) * 3 + c] * a1;
+    return (unsigned int)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// MODE 0: fp32 NCHW (B,3,H,W); MODE 1: fp16 NHWC4 with border P: [B][H+2P][W+2P][4], 4th channel 0
+template <int MODE>
+__device__ __forceinline__ void pre_store(void* out, int b, int y, int x, int H, int W, int P, const float* __restrict__ lut,
+                                          const f16* __restrict__ lut16, unsigned int v0, unsigned int v1, unsigned int v2) {
+    if (MODE == 0) {
+        float* o = (float*)out + (size_t)b * 3 * H * W + (size_t)y * W + x;
+        o[0] = lut[v0]; o[(size_t)H * W] = lut[256 + v1]; o[(size_t)2 * H * W] = lut[512 + v2];
+    } else {
+        const f16x4 px = {lut16[v0], lut16[256 + v1], lut16[512 + v2], (f16)0.f};
+        *(f16x4*)((f16*)out + (((size_t)b * (H + 2 * P) + y + P) * (W + 2 * P) + x + P) * 4) = px;
+    }
+}
+
+// interior: one thread per pixel of the resized image (grid.y = image); per-image channel sums via LDS + 3 atomics per block
+template <int MODE>
+__global__ __launch_bounds__(256) void pre_interior_kernel(const PreBatch pb, void* __restrict__ out, int H, int W, int P,
+                                                          const float* __restrict__ lut, const f16* __restrict__ lut16,
+                                                          unsigned long long* __restrict__ sums) {
+    const int b = blockIdx.y;
+    const int rh = pb.rh[b], rw = pb.rw[b], h = pb.h[b], w = pb.w[b];
+    const uint8_t* img = pb.img[b];
+    const int npix = rh * rw;
+    const double sx_scale = (double)w / (double)rw, sy_scale = (double)h / (double)rh;
+    const int pad_h = (H - rh) / 2, pad_w = (W - rw) / 2;
+    unsigned int s0 = 0, s1 = 0, s2 = 0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int y = p / rw, x = p - y * rw;
+        unsigned int v0, v1, v2;
+        if (rh == h && rw == w) {
+            const uint8_t* s = img + (size_t)p * 3;
+            v0 = s[0]; v1 = s[1]; v2 = s[2];
+        } else {
+            int x0, x1, a0, a1, y0, y1, b0, b1;
+            resize_coef(x, sx_scale, w, x0, x1, a0, a1);
+            resize_coef(y, sy_scale, h, y0, y1, b0, b1);
+            v0 = resized_pixel(img, w, 0, y0, y1, b0, b1, x0, x1, a0, a1);
+            v1 = resized_pixel(img, w, 1, y0, y1, b0, b1, x0, x1, a0, a1);
+            v2 = resized_pixel(img, w, 2, y0, y1, b0, b1, x0, x1, a0, a1);
+        }
+        s0 += v0; s1 += v1; s2 += v2;
+        pre_store<MODE>(out, b, y + pad_h, x + pad_w, H, W, P, lut, lut16, v0, v1, v2);
+    }
+    __shared__ unsigned int sh[3][256];
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) for (int c = 0; c < 3; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) atomicAdd(&sums[b * 3 + threadIdx.x], (unsigned long long)sh[threadIdx.x][0]);
+}
+
+// border: the canvas pixels outside the centred image get np.full(..., cv2.mean(img)[:3], dtype=np.uint8) of the RESIZED image
+template <int MODE>
+__global__ __launch_bounds__(256) void pre_border_kernel(const PreBatch pb, void* __restrict__ out, int H, int W, int P,
+                                                        const float* __restrict__ lut, const f16* __restrict__ lut16,
+                                                        const unsigned long long* __restrict__ sums) {
+    const int b = blockIdx.y;
+    const int rh = pb.rh[b], rw = pb.rw[b];
+    const int pad_h = (H - rh) / 2, pad_w = (W - rw) / 2;
+    const int nborder = H * W - rh * rw;
+    const unsigned long long npix = (unsigned long long)rh * rw;
+    const unsigned int m0 = (unsigned int)(sums[b * 3] / npix), m1 = (unsigned int)(sums[b * 3 + 1] / npix), m2 = (unsigned int)(sums[b * 3 + 2] / npix);
+    // enumerate border pixels: rows above, rows below, then the left/right strips of the image rows
+    const int top = pad_h * W, bot = (H - pad_h - rh) * W, side = W - rw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nborder; i += gridDim.x * 256) {
+        int y, x;
+        if (i < top) { y = i / W; x = i - y * W; }
+        else if (i < top + bot) { const int j = i - top; y = pad_h + rh + j / W; x = j - (j / W) * W; }
+        else { const int j = i - top - bot; const int r = j / side, q = j - r * side; y = pad_h + r; x = q < pad_w ? q : q + rw; }
+        pre_store<MODE>(out, b, y, x, H, W, P, lut, lut16, m0, m1, m2);
+    }
+}
+
+extern "C" int rtm3d_preprocess_batch(void* stream, int B, const uint8_t* const* h_imgs, const int* h_hw, const int* h_resized_hw,
+                                      void* d_out, int out_mode, int H, int W, int out_border, const float* d_lut,
+                                      const void* d_lut16, unsigned long long* d_sums) {
+    if (B < 1 || !h_imgs || !h_hw || !d_out || !d_lut || !d_sums) { rt_set_error("preprocess_batch: bad arguments"); return 1; }
+    if (out_mode != 0 && out_mode != 1) { rt_set_error("preprocess_batch: out_mode must be 0 (fp32 NCHW) or 1 (fp16 NHWC4)"); return 1; }
+    if (out_mode == 1 && (!d_lut16 || out_border < 0)) { rt_set_error("preprocess_batch: the NHWC4 output needs the fp16 table and a border >= 0"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_sums, 0, (size_t)B * 3 * sizeof(unsigned long long), s) != hipSuccess) { rt_set_error("preprocess_batch: memset failed"); return 1; }
+    for (int b0 = 0; b0 < B; b0 += PRE_MAX_BATCH) {
+        const int nb = B - b0 < PRE_MAX_BATCH ? B - b0 : PRE_MAX_BATCH;
+        PreBatch pb;
+        int max_in = 0, max_border = 0;
+        for (int i = 0; i < nb; ++i) {
+            const int h = h_hw[2 * (b0 + i)], w = h_hw[2 * (b0 + i) + 1];
+            const int rh = h_resized_hw ? h_resized_hw[2 * (b0 + i)] : h, rw = h_resized_hw ? h_resized_hw[2 * (b0 + i) + 1] : w;
+            if (!h_imgs[b0 + i] || h < 1 || w < 1 || rh < 1 || rw < 1 || rh > H || rw > W) {
+                rt_set_error("preprocess_batch: image %d (%dx%d -> %dx%d) does not fit the %dx%d canvas", b0 + i, h, w, rh, rw, H, W);
+                return 1;
+            }
+            pb.img[i] = h_imgs[b0 + i]; pb.h[i] = h; pb.w[i] = w; pb.rh[i] = rh; pb.rw[i] = rw;
+            max_in = rh * rw > max_in ? rh * rw : max_in;
+            max_border = H * W - rh * rw > max_border ? H * W - rh * rw : max_border;
+        }
+        // offsets of this sub-batch in the outputs
+        void* o = out_mode == 0 ? (void*)((float*)d_out + (size_t)b0 * 3 * H * W)
+                                : (void*)((f16*)d_out + (size_t)b0 * (H + 2 * out_border) * (W + 2 * out_border) * 4);
+        unsigned long long* sm = d_sums + (size_t)b0 * 3;
+        int bx = (max_in + 255) / 256;
+        bx = bx > 512 ? 512 : bx;
+        if (out_mode == 0) hipLaunchKernelGGL(pre_interior_kernel<0>, dim3(bx, nb), dim3(256), 0, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
+        else hipLaunchKernelGGL(pre_interior_kernel<1>, dim3(bx, nb), dim3(256), 0, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
+        if (max_border > 0) {
+            int gx = (max_border + 255) / 256;
+            gx = gx > 256 ? 256 : gx;
+            if (out_mode == 0) hipLaunchKernelGGL(pre_border_kernel<0>, dim3(gx, nb), dim3(256), 0, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
+            else hipLaunchKernelGGL(pre_border_kernel<1>, dim3(gx, nb), dim3(256), 0, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("preprocess_batch launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}

@@ -415,7 +415,8 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
-        case OP_INPUT4: e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
+        case OP_INPUT4: if (!d_in) break;        // the input tensor was filled by rtm3d_preprocess_batch (out_mode 1)
+            e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
         case OP_HEADOUT: {
             HeadOutArgs a = op.ho;
             for (int i = 0; i < 4; ++i) a.out[i] = d_out[i];
@@ -448,7 +449,7 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
 static const size_t GRAPH_CACHE = 8;
 
 extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
-    if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward: null argument");
+    if (!ctx || !d_out_logits) RT_FAIL("forward: null argument");
     if (!d_out_logits[0]) RT_FAIL("forward: null logits buffer 0");
     if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
     hipStream_t s = (hipStream_t)stream;
@@ -486,6 +487,16 @@ extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, fl
     return 0;
 }
 
+extern "C" int rtm3d_input_tensor(rtm3d_ctx* ctx, void** d_base, int* B, int* H, int* W, int* border) {
+    if (!ctx || !d_base || !B || !H || !W || !border) RT_FAIL("input_tensor: null argument");
+    for (auto& op : ctx->ops)
+        if (op.kind == OP_INPUT4) {
+            *d_base = op.stem.out; *B = op.stem.B; *H = op.stem.H; *W = op.stem.W; *border = op.stem.out_P;
+            return 0;
+        }
+    RT_FAIL("input_tensor: the plan has no NHWC4 input tensor");
+}
+
 extern "C" int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable) {
     if (!ctx) RT_FAIL("ctx_set_graph: null context");
     ctx->graph_mode = enable ? 1 : 0;
@@ -520,7 +531,7 @@ extern "C" int rtm3d_probe_read(rtm3d_ctx* ctx, double* avg_ms, int* count) {
 
 extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
                                    float* h_ms, int cap, int* n_ops) {
-    if (!ctx || !d_in || !d_out_logits) RT_FAIL("forward_timed: null argument");
+    if (!ctx || !d_out_logits) RT_FAIL("forward_timed: null argument");
     const int n = (int)ctx->ops.size();
     if (n_ops) *n_ops = n;
     if (!h_ms) return 0;

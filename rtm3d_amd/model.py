@@ -159,16 +159,36 @@ class Model(object):
             x = x.float()
         return x.contiguous()
 
-    def forward_logits(self, x):
-        """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23)."""
-        x = self._check_input(x)
-        B, _, H, W = x.shape
-        dev = x.device
+    def input_tensor(self, B, H, W, device=None):
+        """(device address, border) of the fp16 NHWC4 input tensor of the plan for (B, H, W): the target of
+        ``rtm3d_amd.preprocess.preprocess_batch(..., model=self)``."""
+        dev = torch.device(device) if device is not None else self._device
+        if dev is None or dev.type != 'cuda':
+            raise RuntimeError('rtm3d_amd.Model.input_tensor needs a CUDA (ROCm) device; call model.to("cuda") first')
+        dev = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
+        return self._plan_for(B, H, W, dev).input_tensor()
+
+    def forward_logits(self, x, preloaded=None):
+        """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23).
+        preloaded=(B, H, W): ``x`` is None and the plan's input tensor was filled by preprocess_batch(model=self)."""
+        if preloaded is not None:
+            if x is not None:
+                raise ValueError('forward_logits: pass x=None with preloaded=(B, H, W)')
+            B, H, W = (int(v) for v in preloaded)
+            dev = self._device
+            if dev is None:
+                raise RuntimeError('forward_logits(preloaded=...): call model.to("cuda") first')
+            xptr = 0
+        else:
+            x = self._check_input(x)
+            B, _, H, W = x.shape
+            dev = x.device
+            xptr = x.data_ptr()
         plan = self._plan_for(B, H, W, dev)
         with torch.cuda.device(dev):
             outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in self._head_channels]
             ptrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
-            plan.forward(torch.cuda.current_stream(dev).cuda_stream, x.data_ptr(), ptrs)
+            plan.forward(torch.cuda.current_stream(dev).cuda_stream, xptr, ptrs)
         return tuple(outs)
 
     def forward(self, x):

@@ -589,6 +589,14 @@ class RealizedPlan(object):
             info.append({'kernel': nm.value.decode(), 'name': self.plan.ops[i]['name'], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
         return info
 
+    def input_tensor(self):
+        """(device address, border) of the fp16 NHWC4 tensor the stem reads (rtm3d_input_tensor)."""
+        base, B, H, W, P = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.rtm3d_input_tensor(self.ctx, ctypes.byref(base), ctypes.byref(B), ctypes.byref(H), ctypes.byref(W),
+                                               ctypes.byref(P)), 'input_tensor')
+        assert (B.value, H.value, W.value) == (self.plan.B, self.plan.H, self.plan.W)
+        return base.value, P.value
+
     def set_graph(self, enable):
         """Replay the plan as one hipGraph launch (bit-identical results; see rtm3d_ctx_set_graph)."""
         _lib.check(self.lib.rtm3d_ctx_set_graph(self.ctx, 1 if enable else 0), 'ctx_set_graph')

@@ -31,7 +31,10 @@ def _stub(name, **attrs):
 tv = _stub('torchvision'); tvt = _stub('torchvision.transforms', ToTensor=lambda: None); tv.transforms = tvt
 _stub('albumentations')
 cv2 = _stub('cv2', mean=lambda img: tuple(np.asarray(img, np.float64).reshape(-1, img.shape[2]).mean(axis=0)) + (0.0,) * (4 - img.shape[2]),
-            INTER_LINEAR=1)
+            INTER_LINEAR=1,
+            # size bookkeeping only: lets the reference's own Resize.__call__ run so that its dsize rule and the K scaling of
+            # ToPercentCoords/ToAbsoluteCoords are pinned; the interpolated pixel values cannot be (OpenCV is absent)
+            resize=lambda src, dsize, interpolation: np.zeros((dsize[1], dsize[0], src.shape[2]), src.dtype))
 for n in ('datasets.data', 'datasets.data.kitti', 'datasets.data.kitti.devkit_object', 'datasets.data.kitti.devkit_object.utils'):
     _stub(n)
 sys.modules['datasets.data.kitti.devkit_object'].utils = sys.modules['datasets.data.kitti.devkit_object.utils']
@@ -69,5 +72,17 @@ for i, (h, w, H, W) in enumerate(cases):
     else:
         out['x_%d_sub' % i] = x[:, ::7, ::11].copy()
         out['x_%d_sum' % i] = x.astype(np.float64).sum(axis=(1, 2))
+# Resize bookkeeping through the reference's TestTransform chain (preprocess/data_preprocess.py:35-44):
+# ToPercentCoords -> Resize(size) -> ToAbsoluteCoords on (image shape, K)
+rs_cases = [(375, 1242, 1280), (370, 1224, 1280), (376, 1241, 1280), (100, 57, 64), (480, 640, 1280), (1, 1, 32)]
+out['rs_cases'] = np.array(rs_cases)
+for i, (h, w, size) in enumerate(rs_cases):
+    img = np.zeros((h, w, 3), np.uint8)
+    tgt = ParamList((w, h))
+    tgt.add_field('K', np.array([[721.5377, 0, 609.5593, 0, 721.5377, 172.854, 0, 0, 1]]))
+    for tr in (ref_t.ToPercentCoords(), ref_t.Resize(size), ref_t.ToAbsoluteCoords()):
+        img, tgt = tr(img, tgt)
+    out['rs_size_%d' % i] = np.array(img.shape[:2])
+    out['rs_K_%d' % i] = tgt.get_field('K')
 np.savez_compressed(os.path.join(HERE, 'preprocess_cases.npz'), **out)
 print('ok', {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
