@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
+    ap.add_argument('--v2-min-tiles', type=int, default=None, help='DIAGNOSTIC: fewest 256x256 tiles a layer needs to go to the persistent conv256 kernel (plan.V2_MIN_TILES)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
 
@@ -285,6 +286,9 @@ def main():
 
     import rtm3d_amd
     from rtm3d_amd import weights, distributed as rdist
+    if args.v2_min_tiles is not None:
+        from rtm3d_amd import plan as _plan
+        _plan.V2_MIN_TILES = args.v2_min_tiles
     bb = args.backbone
     B, H, W = args.batch, args.height, args.width
     cfg = rtm3d_amd.kitti_config(bb)
@@ -401,6 +405,8 @@ def main():
                'roofline': roof, 'multi_gpu': multi}
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'
+        if args.v2_min_tiles is not None:
+            out['DIAGNOSTIC_v2_min_tiles'] = args.v2_min_tiles
         if args.heat_bias is not None:
             out['DIAGNOSTIC'] = 'heat-map bias overridden to %g (not the benchmark workload)' % args.heat_bias
         if args.per_op:

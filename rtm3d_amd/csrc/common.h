@@ -51,8 +51,6 @@ struct ConvKArgs {
     int ntaps;
     int relu, MT, NT;
     int out_H, out_W;             // NCHW fp32 epilogue only
-    int tile_band;                // persistent conv256, NT > 1: 0 = all channel tiles of a pixel tile adjacent; b > 0 = per band of b
-                                  // pixel tiles, channel-tile-major (the CUs of an XCD then stream ONE channel tile's weights at a time)
     ConvGroupArgs g[RT_MAX_GROUPS];
 };
 

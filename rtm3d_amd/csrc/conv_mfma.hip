@@ -14,10 +14,7 @@
 //
 // Replaces the stock ATen conv2d / conv_transpose2d calls of models/nets/{dla,resnet,header,
 // keypoint_fpn_fusion,module}.py.
-#include <stdlib.h>
 #include "common.h"
-
-#define CONV_RING_DEFAULT 3
 
 #define LDS_AS __attribute__((address_space(3)))
 #define GLB_AS __attribute__((address_space(1)))
@@ -208,191 +205,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Ring form of the 128-pixel kernel (BN = 64 / 128, fp16 NHWC epilogue): NST K-step buffers instead of two, the
-// LDS-DMA of K-step ks + NST - 1 is issued right after the barrier that opens K-step ks, and the wait in front of
-// that barrier is a COUNTED s_waitcnt that only retires K-step ks's own pieces - so NST - 2 whole K-steps stay in
-// flight across barriers, and there is one barrier per K-step instead of a full drain (vmcnt(0)) + __syncthreads.
-// Why: measured on the backbone 3x3 layers the two-buffer kernel spends ~1.1 us per K-step against 0.25 us of
-// MFMA work (levels 3-5 at 590-860 TFLOP/s): with one K-step in flight per workgroup the loop runs at the DMA
-// latency.  The DMA is issued from inline asm (see conv_mfma256.hip: a visible LDS-DMA makes the compiler put
-// s_waitcnt vmcnt(0) in front of every operand read) and the operand reads go through integer LDS addresses.
-#define RING_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
-#define RING_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
-
-template <int BN, int NST, int RES>
-__global__ __launch_bounds__(256) void conv_mfma_ring_kernel(const ConvKArgs a) {
-    constexpr int BM = 128, WGM = 2, WGN = 2;
-    constexpr int XI = BM * 8 / 256;           // 4 pixel pieces per thread and K-step
-    constexpr int WI = BN * 8 / 256;           // 2 or 4 weight pieces
-    constexpr int DPS = XI + WI;               // DMA instructions per wave and K-step
-    constexpr int TP = BM / WGM / 16, TC = BN / WGN / 16;
-    constexpr int STAGE = (BM + BN) * 64;      // halves per K-step buffer
-    static_assert(BN == 64 || BN == 128, "ring kernel: BN must be 64 or 128");
-    __shared__ __attribute__((aligned(16))) f16 lds[NST * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave / WGN, wc = wave % WGN;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int chunk = (a.MT + 7) >> 3;
-    const int ntile = j % a.NT;
-    const int mtile = xcd * chunk + j / a.NT;
-    if (mtile >= a.MT) return;
-    const ConvGroupArgs& g = a.g[blockIdx.y];
-    const int T = a.ksteps;
-
-    uint32_t xoff[XI];
-    {
-        const int rr = tid >> 3, cs = tid & 7;
-        const float rcp_hw0 = 1.0f / (float)a.HmWm, rcp_w0 = 1.0f / (float)a.Wm;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            int m = mtile * BM + i * 32 + rr;
-            m = m < a.M ? m : a.M - 1;
-            const int n = div_small_q(m, a.HmWm, rcp_hw0), rem = m - n * a.HmWm;
-            const int y = div_small_q(rem, a.Wm, rcp_w0), x = rem - y * a.Wm;
-            const uint32_t pix = (uint32_t)((n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P);
-            xoff[i] = pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8);
-        }
-    }
-    const f16* wbase = a.wgt + g.w_off + (size_t)ntile * T * (BN * 64);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
-
-    auto stage = [&](int buf, int ks) {
-        const int tap = ks / a.cpt, q = ks - tap * a.cpt;
-        const int koff = g.tap_off[tap] + q * 64;
-        const uint32_t xl = lds_base + (uint32_t)(buf * STAGE) * 2u;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const f16* src = a.in + (size_t)xoff[i] + (ptrdiff_t)koff;
-            RING_DMA16(src, __builtin_amdgcn_readfirstlane(xl + (uint32_t)((i * 256 + wave * 64) * 16)));
-        }
-        const f16* ws = wbase + (size_t)ks * (BN * 64);
-        const uint32_t wl = xl + BM * 64 * 2;
-#pragma unroll
-        for (int i = 0; i < WI; ++i)
-            RING_DMA16(ws + (i * 256 + tid) * 8, __builtin_amdgcn_readfirstlane(wl + (uint32_t)((i * 256 + wave * 64) * 16)));
-    };
-
-    f32x4 acc[TC][TP];
-#pragma unroll
-    for (int c = 0; c < TC; ++c)
-#pragma unroll
-        for (int p = 0; p < TP; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fk = lane >> 4;
-    const uint32_t sw0 = (uint32_t)(((0 * 4 + fk) ^ (frow & 7)) * 16), sw1 = (uint32_t)(((1 * 4 + fk) ^ (frow & 7)) * 16);
-    const uint32_t xrow_b = (uint32_t)((wp * (BM / WGM) + frow) * 128);
-    const uint32_t wrow_b = (uint32_t)(BM * 128 + (wc * (BN / WGN) + frow) * 128);
-
-    // prologue: K-steps 0 .. NST-2 in flight
-#pragma unroll
-    for (int s0 = 0; s0 < NST - 1; ++s0)
-        if (s0 < T) stage(s0, s0);
-    int buf = 0;                                // ring slot of K-step ks
-    for (int ks = 0; ks < T; ++ks) {
-        // retire K-step ks: everything issued later may stay in flight.  K-steps issued so far: 0 .. min(T, ks+NST-1) - 1
-        const int later = (T - 1 - ks) < (NST - 2) ? (T - 1 - ks) : (NST - 2);
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * DPS) : "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();           // every wave's pieces of K-step ks have landed; slot (ks-1) % NST is free
-        __builtin_amdgcn_sched_barrier(0);
-        int nb = buf + NST - 1;
-        nb = nb >= NST ? nb - NST : nb;
-        if (ks + NST - 1 < T) stage(nb, ks + NST - 1);
-        const uint32_t xb = lds_base + (uint32_t)(buf * STAGE) * 2u;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t sw = kk ? sw1 : sw0;
-            f16x8 xf[TP], wf[TC];
-#pragma unroll
-            for (int p = 0; p < TP; ++p) xf[p] = RING_LDS_F16X8(xb + xrow_b + p * 2048 + sw);
-#pragma unroll
-            for (int c = 0; c < TC; ++c) wf[c] = RING_LDS_F16X8(xb + wrow_b + c * 2048 + sw);
-#pragma unroll
-            for (int c = 0; c < TC; ++c)
-#pragma unroll
-                for (int p = 0; p < TP; ++p)
-                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], xf[p], acc[c][p], 0, 0, 0);
-        }
-        buf = buf + 1 == NST ? 0 : buf + 1;
-    }
-
-    // ---- epilogue (as conv_mfma_kernel, EPI = 0): loads first, then one run of 16-byte stores
-    const float rcp_hw = 1.0f / (float)a.HmWm, rcp_w = 1.0f / (float)a.Wm;
-    const int cw = ntile * BN + wc * (BN / WGN);
-    f32x4 bv[TC];
-#pragma unroll
-    for (int c = 0; c < TC; ++c) bv[c] = *(const f32x4*)(a.bias + g.bias_off + cw + c * 16 + fk * 4);
-    const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
-    const f16x4 lo4 = {lo, lo, lo, lo};
-    size_t opix[TP];
-    f16x4 rv[TP][TC];
-#pragma unroll
-    for (int p = 0; p < TP; ++p) {
-        int m = mtile * BM + wp * (BM / WGM) + p * 16 + frow;
-        m = m < a.M ? m : a.M - 1;              // rows past M hold pixel M-1's result: a same-value write
-        const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
-        const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
-        const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
-        opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + cw;
-        if (RES) {
-            const f16* rp = a.res + ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff + cw + fk * 4;
-#pragma unroll
-            for (int c = 0; c < TC; ++c) rv[p][c] = *(const f16x4*)(rp + c * 16);
-        }
-    }
-    const int so = (fk & 1) * 16 + (fk >> 1) * 8;
-#pragma unroll
-    for (int p = 0; p < TP; ++p) {
-        f16x4 h[TC];
-#pragma unroll
-        for (int c = 0; c < TC; ++c) {
-            f32x4 v = acc[c][p] + bv[c];
-            if (RES) {
-                const f16x4 r = rv[p][c];
-                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-            }
-            const f16x4 t = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            h[c] = __builtin_elementwise_max(t, lo4);
-        }
-#pragma unroll
-        for (int c = 0; c < TC; c += 2) {
-            uint32_t u0[2], u1[2];
-            __builtin_memcpy(u0, &h[c], 8);
-            __builtin_memcpy(u1, &h[c + 1], 8);
-            const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
-            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-            *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;
-        }
-    }
-}
-
-static int conv_ring_stages() {
-    static int nst = -1;
-    if (nst < 0) {
-        const char* e = getenv("RTM3D_CONV_RING");          // A/B switch: 0 = two-buffer kernel, 3 = three-slot ring
-        nst = e ? atoi(e) : CONV_RING_DEFAULT;
-    }
-    return nst;
-}
-
-template <int BN>
-static hipError_t launch_ring(const ConvKArgs& a, int groups, hipStream_t s) {
-    const int mt8 = (a.MT + 7) / 8 * 8;
-    dim3 grid(mt8 * a.NT, groups, 1), block(256, 1, 1);
-    if (a.res) hipLaunchKernelGGL((conv_mfma_ring_kernel<BN, 3, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_mfma_ring_kernel<BN, 3, 0>), grid, block, 0, s, a);
-    return hipGetLastError();
-}
-
 template <int BM, int BN, int WGM, int WGN>
 static hipError_t launch_t(const ConvKArgs& a, int groups, int epi, hipStream_t s) {
     const int mt8 = (a.MT + 7) / 8 * 8;
@@ -407,11 +219,6 @@ static hipError_t launch_t(const ConvKArgs& a, int groups, int epi, hipStream_t 
 }
 
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s) {
-    // the ring kernel assumes full channel tiles (cout % BN == 0: true for every fp16-NHWC layer) and >= 2 K-steps
-    if (!epi_nchw && conv_ring_stages() == 3 && a.ksteps >= 2 && (a.cout % bn_tile) == 0) {
-        if (bn_tile == 128) return launch_ring<128>(a, groups, s);
-        if (bn_tile == 64) return launch_ring<64>(a, groups, s);
-    }
     switch (bn_tile) {
         case 128: return launch_t<128, 128, 2, 2>(a, groups, epi_nchw, s);
         case 64: return launch_t<128, 64, 2, 2>(a, groups, epi_nchw, s);

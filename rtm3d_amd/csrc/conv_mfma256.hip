@@ -16,7 +16,6 @@
 //   * raw s_barrier twice per phase (after the load segment, after the MFMA segment); waves 4-7
 //     run one barrier behind waves 0-3, so on every SIMD one wave issues MFMAs while its partner
 //     issues LDS reads / DMA / waits (the two co-resident waves of a SIMD share one matrix pipe).
-#include <stdlib.h>
 #include "common.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // non-zero data they run at the rate the chip's power management allows (1.9 GHz in-kernel clock;
 // the same binary on all-zero activations: 1.64 PFLOP/s).
 #define CONV256_MAX_BIAS 2048
-#define CONV256_DEFAULT_BAND 0
 // LDS-DMA as inline asm (m0 = LDS base of the wave's 1 KB run, one 16-byte piece per lane).  The compiler
 // must not know these write LDS: its waitcnt pass treats every visible ds_read as possibly aliasing a pending
 // LDS-DMA and puts s_waitcnt vmcnt(0) in front of it, draining the DMA ring in every phase; ordering against
@@ -345,18 +343,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     auto locate = [&](int vv, uint32_t (&xo)[2][2], const f16*& wb, int& gi, int& mt, int& nt) {
         gi = vv / jbs;
         const int jb = vv - gi * jbs;
-        int q;
-        if (a.tile_band > 0) {
-            const int bsz = a.tile_band * a.NT;
-            const int band = jb / bsz, r = jb - band * bsz;
-            int mb = mt_here - band * a.tile_band;            // pixel tiles in this band (the last one may be short)
-            mb = mb > a.tile_band ? a.tile_band : mb;
-            nt = r / mb;
-            q = band * a.tile_band + (r - nt * mb);
-        } else {
-            q = jb / a.NT;
-            nt = jb - q * a.NT;
-        }
+        const int q = jb / a.NT;
+        nt = jb - q * a.NT;
         mt = xcd * chunk + q;
         const ConvGroupArgs& g = a.g[gi];
 #pragma unroll
@@ -546,18 +534,6 @@ static int device_cu_count() {
     return n;
 }
 
-// Tile order of the persistent kernel for layers with several channel tiles (head d6: NT = 4): RTM3D_CONV256_BAND
-// overrides the built-in default (A/B switch for the L2-residency experiment, DESIGN.md "Rejected / kept").
-static int conv256_tile_band() {
-    static int band = -1;
-    if (band < 0) {
-        const char* e = getenv("RTM3D_CONV256_BAND");
-        band = e ? atoi(e) : CONV256_DEFAULT_BAND;
-        if (band < 0) band = 0;
-    }
-    return band;
-}
-
 // Whether launch_conv_mfma256 sends this conv to the halo-tile kernel (the only one that can emit the
 // spatial-softmax partials of its output, `stat_out`).
 bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups) {
@@ -582,10 +558,8 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
         dim3 grid(per_xcd * 8, 1, 1);
-        ConvKArgs b = a;
-        b.tile_band = a.NT > 1 ? conv256_tile_band() : 0;
-        if (a.res) hipLaunchKernelGGL(conv_mfma256_persistent_kernel<1>, grid, block, 0, s, b, groups, nbias, tile_ctr);
-        else hipLaunchKernelGGL(conv_mfma256_persistent_kernel<0>, grid, block, 0, s, b, groups, nbias, tile_ctr);
+        if (a.res) hipLaunchKernelGGL(conv_mfma256_persistent_kernel<1>, grid, block, 0, s, a, groups, nbias, tile_ctr);
+        else hipLaunchKernelGGL(conv_mfma256_persistent_kernel<0>, grid, block, 0, s, a, groups, nbias, tile_ctr);
         return hipGetLastError();
     }
     if (stat_out) return hipErrorInvalidValue;       // only the halo kernel writes softmax partials

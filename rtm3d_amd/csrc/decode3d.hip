@@ -41,10 +41,14 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 }
 
 // One wavefront per object (lbfgsb_wave.h): the production kernel.  A workgroup packs D3_WPB objects
-// (8 waves, 90 KB of LDS): the ~15 objects of an image then sit on two CUs instead of fifteen, which
+// (8 waves, 67 KB of LDS): the ~15 objects of an image then sit on two CUs instead of fifteen, which
 // matters when this kernel runs beside the forward pass of the next batch - a CU that holds even one
 // of these waves cannot take a workgroup of the persistent conv kernel until the wave retires.
-#define D3_WPB 8
+// Measured per pipelined step (bs=32, profiles/r02_decode3d_load.json): 8 objects per workgroup (178 VGPRs, no
+// scratch) 15.62 ms at 473 objects / 18.03 ms at 3200; 12 (168-VGPR cap) 16.02 / 18.40; 16 (128-VGPR cap,
+// 132 B of spills per lane) 16.12 / 18.49: the spills cost more than the denser packing saves.
+#define D3_WPB_DEFAULT 8
+template <int D3_WPB>
 __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
                                                            const double* __restrict__ dim_ref, int ncls,
@@ -83,6 +87,9 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
 
 extern void rt_set_error(const char* fmt, ...);
 
+#define D3_LAUNCH(...) hipLaunchKernelGGL(decode3d_wave_kernel<D3_WPB_DEFAULT>, dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
+                                          dim3(64 * D3_WPB_DEFAULT), 0, (hipStream_t)stream, __VA_ARGS__)
+
 extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                               const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                               double* d_fun, int32_t* d_nit, int32_t* d_status) {
@@ -91,8 +98,7 @@ extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const f
     if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
         rt_set_error("decode3d: null pointer"); return 1;
     }
-    hipLaunchKernelGGL(decode3d_wave_kernel, dim3((N + D3_WPB - 1) / D3_WPB), dim3(64 * D3_WPB), 0, (hipStream_t)stream, N, d_cls, d_verts,
-                       d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    D3_LAUNCH(N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
@@ -107,8 +113,7 @@ extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t
         rt_set_error("decode3d_slots: null pointer"); return 1;
     }
     const int N = B * topk;
-    hipLaunchKernelGGL(decode3d_wave_kernel, dim3((N + D3_WPB - 1) / D3_WPB), dim3(64 * D3_WPB), 0, (hipStream_t)stream, N, d_cls, d_verts,
-                       d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
+    D3_LAUNCH(N, d_cls, d_verts, d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d_slots launch: %s", hipGetErrorString(e)); return 1; }
     return 0;

@@ -217,12 +217,14 @@ LB_HD static inline void lb_dcstep(double* stx, double* fx, double* dx, double* 
         } else if (*stp > *stx) stpf = stpmax;
         else stpf = stpmin;
     }
-    if (fp > *fx) {
-        *sty = *stp; *fy = fp; *dy = dp;
-    } else {
-        if (sgnd < 0.0) { *sty = *stx; *fy = *fx; *dy = *dx; }
-        *stx = *stp; *fx = fp; *dx = dp;
-    }
+    // interval update by value selection (with stores through either the x or the y pointers per branch the compiler
+    // selects the POINTER at run time and the six doubles end up in scratch memory on the GPU)
+    const bool hi = fp > *fx, flip = !hi && sgnd < 0.0;
+    const double stx0 = *stx, fx0 = *fx, dx0 = *dx, stp0 = *stp;
+    const double nsty = hi ? stp0 : (flip ? stx0 : *sty), nfy = hi ? fp : (flip ? fx0 : *fy), ndy = hi ? dp : (flip ? dx0 : *dy);
+    const double nstx = hi ? stx0 : stp0, nfx = hi ? fx0 : fp, ndx = hi ? dx0 : dp;
+    *sty = nsty; *fy = nfy; *dy = ndy;
+    *stx = nstx; *fx = nfx; *dx = ndx;
     *stp = stpf;
 }
 
@@ -249,16 +251,23 @@ LB_HD static inline int lb_dcsrch(double f, double g, double* stp, double ftol, 
     if (*stp == stpmin && (f > ftest || g >= S->gtest)) task = LS_WARN;
     if (f <= ftest && fabs(g) <= gtol * (-S->ginit)) task = LS_CONV;
     if (task != LS_FG) return task;
-    if (S->stage == 1 && f <= S->fx && f > ftest) {
-        const double fm = f - *stp * S->gtest;
-        double fxm = S->fx - S->stx * S->gtest, fym = S->fy - S->sty * S->gtest;
-        const double gm = g - S->gtest;
-        double gxm = S->gx - S->gtest, gym = S->gy - S->gtest;
-        lb_dcstep(&S->stx, &fxm, &gxm, &S->sty, &fym, &gym, stp, fm, gm, &S->brackt, S->stmin, S->stmax);
-        S->fx = fxm + S->stx * S->gtest; S->fy = fym + S->sty * S->gtest;
-        S->gx = gxm + S->gtest; S->gy = gym + S->gtest;
+    // One call of dcstep on local copies (selected VALUES, not selected pointers: with `&fxm` / `&S->fx` chosen per
+    // branch the compiler merged the two inlined call sites and kept the bracket state in scratch memory behind a
+    // run-time pointer - 2 x 40 B of private memory per lane on the GPU, touched in every line-search step).
+    const bool modified = S->stage == 1 && f <= S->fx && f > ftest;
+    double fx_l = S->fx, fy_l = S->fy, gx_l = S->gx, gy_l = S->gy, fp_l = f, gp_l = g;
+    if (modified) {
+        fp_l = f - *stp * S->gtest;
+        fx_l = S->fx - S->stx * S->gtest; fy_l = S->fy - S->sty * S->gtest;
+        gp_l = g - S->gtest;
+        gx_l = S->gx - S->gtest; gy_l = S->gy - S->gtest;
+    }
+    lb_dcstep(&S->stx, &fx_l, &gx_l, &S->sty, &fy_l, &gy_l, stp, fp_l, gp_l, &S->brackt, S->stmin, S->stmax);
+    if (modified) {
+        S->fx = fx_l + S->stx * S->gtest; S->fy = fy_l + S->sty * S->gtest;
+        S->gx = gx_l + S->gtest; S->gy = gy_l + S->gtest;
     } else {
-        lb_dcstep(&S->stx, &S->fx, &S->gx, &S->sty, &S->fy, &S->gy, stp, f, g, &S->brackt, S->stmin, S->stmax);
+        S->fx = fx_l; S->fy = fy_l; S->gx = gx_l; S->gy = gy_l;
     }
     if (S->brackt) {
         if (fabs(S->sty - S->stx) >= p66 * S->width1) *stp = S->stx + p5 * (S->sty - S->stx);

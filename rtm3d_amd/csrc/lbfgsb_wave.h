@@ -23,7 +23,10 @@
 struct LbWaveMem {
     double ws[LB_N * LB_M], wy[LB_N * LB_M];
     double sy[LB_M * LB_M], ss[LB_M * LB_M], wt[LB_M * LB_M];
-    double wn[LB_M2 * LB_M2], wn1[LB_M2 * LB_M2];
+    // WN (upper triangle incl. diagonal: the matrix formk factorises in place) and WN1 (lower triangles of its (1,1) and
+    // (2,2) blocks + the full (2,1) block: the running sums formk updates incrementally) share ONE 20 x 20 array; only
+    // WN1's diagonal needs a home of its own.  8.4 KB per object instead of 11.4: 16 objects per workgroup.
+    double wn[LB_M2 * LB_M2], wn1d[LB_M2];
     double x[LB_N], z[LB_N], r[LB_N], d[LB_N], t[LB_N], g[LB_N], wv[LB_M2];
     double terms[64], fterms[16], bc[2];
     double uv[16];
@@ -34,7 +37,7 @@ struct LbWaveMem {
 #define VSS_(i, j) w->ss[((j)-1) * LB_M + (i)-1]
 #define VWT_(i, j) w->wt[((j)-1) * LB_M + (i)-1]
 #define VWN_(i, j) w->wn[((j)-1) * LB_M2 + (i)-1]
-#define VWN1_(i, j) w->wn1[((j)-1) * LB_M2 + (i)-1]
+#define VWN1_(i, j) (*((i) == (j) ? &w->wn1d[(i)-1] : &w->wn[((j)-1) * LB_M2 + (i)-1]))      /* i >= j */
 
 struct LbWaveK { double k00, k02, k11, k12; };
 
@@ -204,20 +207,22 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         // and (2,2) blocks, the full (2,1) block); two-phase (read all, then write all); slots are
         // statically indexed so they stay in registers (a scan with a running slot counter went to scratch
         // and cost 14k cycles per iteration)
-        double v[6]; int dst[6]; bool ok[6];
+        double v[6]; int dr[6], dc[6]; bool ok[6];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int e = lane + 64 * r;
             const bool in = e < (m - 1) * (m - 1);
             const int ee = in ? e : 0;
             const int c = ee / (m - 1) + 1, q = ee % (m - 1) + 1;     // column 1..m-1, row index 1..m-1
-            ok[3 * r + 0] = in && q >= c; v[3 * r + 0] = VWN1_(q + 1, c + 1);         dst[3 * r + 0] = (c - 1) * LB_M2 + (q - 1);
-            ok[3 * r + 1] = in && q >= c; v[3 * r + 1] = VWN1_(m + q + 1, m + c + 1); dst[3 * r + 1] = (m + c - 1) * LB_M2 + (m + q - 1);
-            ok[3 * r + 2] = in;           v[3 * r + 2] = VWN1_(m + q + 1, c + 1);     dst[3 * r + 2] = (c - 1) * LB_M2 + (m + q - 1);
+            // (q >= c keeps the first two on or below the diagonal; rows of the third are >= m + 1 > c)
+            const int qs = q >= c ? q : c;
+            ok[3 * r + 0] = in && q >= c; v[3 * r + 0] = VWN1_(qs + 1, c + 1);         dr[3 * r + 0] = qs;     dc[3 * r + 0] = c;
+            ok[3 * r + 1] = in && q >= c; v[3 * r + 1] = VWN1_(m + qs + 1, m + c + 1); dr[3 * r + 1] = m + qs; dc[3 * r + 1] = m + c;
+            ok[3 * r + 2] = in;           v[3 * r + 2] = VWN1_(m + q + 1, c + 1);      dr[3 * r + 2] = m + q;  dc[3 * r + 2] = c;
         }
         WSYNC();
 #pragma unroll
-        for (int q = 0; q < 6; ++q) if (ok[q]) w->wn1[dst[q]] = v[q];
+        for (int q = 0; q < 6; ++q) if (ok[q]) VWN1_(dr[q], dc[q]) = v[q];
         WSYNC();
     }
     {
@@ -312,12 +317,12 @@ __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int 
 __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, int* col, int* head, double* theta,
                                          double rr, double dr, double stp, double dtd, int lane) {
     const int m = LB_M, n = LB_N;
-    if (iupdat <= m) {
-        *col = iupdat;
-        *itail = (*head + iupdat - 2) % m + 1;
-    } else {
-        *itail = *itail % m + 1;
-        *head = *head % m + 1;
+    {   // (value selection, not stores through col / head per branch: see lb_dcstep)
+        const bool grow = iupdat <= m;
+        const int col0 = *col, head0 = *head, itail0 = *itail;
+        *col = grow ? iupdat : col0;
+        *itail = grow ? (head0 + iupdat - 2) % m + 1 : itail0 % m + 1;
+        *head = grow ? head0 : head0 % m + 1;
     }
     if (lane < n) { VWS_(lane + 1, *itail) = w->d[lane]; VWY_(lane + 1, *itail) = w->r[lane]; }
     *theta = rr / dr;

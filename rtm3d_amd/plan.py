@@ -22,6 +22,7 @@ import numpy as np
 from . import _lib
 from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, head_table
 
+V2_MIN_TILES = 512
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
 
@@ -349,13 +350,14 @@ def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d'):
 
 # ------------------------------------------------------------------------------------------ realize
 def choose_bn_tile(cout, M):
-    """Output-channel tile of the MFMA kernel: as wide as the layer allows while still giving
-    >= ~2 workgroups per CU (256 CUs) so small late-stage layers fill the chip."""
+    """Output-channel tile of the MFMA kernel (conv_mfma.hip).  128 channels go with the 256-pixel ring kernel (one
+    8-wave workgroup per CU): taken when the layer still gives about a full round of 256 CUs; otherwise 64-channel tiles
+    of the 128-pixel kernel (2-3 workgroups per CU) so that small late-stage layers fill the chip."""
     if cout < 32:
         return 16
     if cout < 64:
         return 32
-    if cout % 128 == 0 and (M // 128) * (cout // 128) >= 512:
+    if cout % 128 == 0 and ((M + 255) // 256) * (cout // 128) >= 192:
         return 128
     return 64
 
@@ -374,7 +376,7 @@ def choose_variant(cin, cout, M, groups, out_nchw):
         # step, measured twice (one-tile and persistent kernel): early in the forward the 3D decode of the
         # previous batch still holds ~60 CUs, whose waves cannot share a SIMD with this kernel, and with one
         # tile per CU there is nothing for the ticket scheduler to rebalance.)
-        if ((M + 255) // 256) * (cout // 256) * groups >= 512:
+        if ((M + 255) // 256) * (cout // 256) * groups >= V2_MIN_TILES:
             return 2
     return 0
 

@@ -1,7 +1,10 @@
 #!/bin/bash
-# GPU session C: decode3d under saturated top-k (3200 objects/batch) with / without the 3D decode; kernel stats
+# GPU session C: new preprocess tests; decode3d under saturated top-k (3200 objects/batch) with / without the 3D decode
 set -o pipefail
 mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_preprocess.py -m gpu -q -x > gpurun_out/r2_t4.log 2>&1; rc=$?
+tail -4 gpurun_out/r2_t4.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
 B="--steps 10 --warmup 3 --no-cpu-baseline --no-parity"
 export RTM3D_CONV_RING=0
 timeout -k 10 200 python bench.py $B > gpurun_out/r2_c_norm.json 2> gpurun_out/r2_c_norm.err || exit 1
