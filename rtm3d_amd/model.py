@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 from . import plan as plan_mod
+from .weight_cache import WeightCache
 from .weights import parse_backbone, state_dict_spec, synth_state_dict, head_table
 
 
@@ -64,6 +65,7 @@ class Model(object):
         self._device = None
         self._plans = OrderedDict()
         self._ws = {}
+        self._wcache = None
         self.use_graph = None                    # None: automatic (hipGraph replay for batches <= GRAPH_MAX_BATCH)
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
         self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant)
@@ -89,6 +91,7 @@ class Model(object):
                     raise RuntimeError('size mismatch for %s: %s vs %s' % (k, tuple(v.shape), tuple(shape)))
                 new[k] = v.to(torch.int64) if k.endswith('num_batches_tracked') else v.to(torch.float32).contiguous()
         self._sd = new
+        self._wcache = None              # folded / packed weights belong to the old state dict
         self._drop_plans()
         return None
 
@@ -141,13 +144,16 @@ class Model(object):
             while len(self._plans) >= MAX_PLANS:
                 old = next(iter(self._plans))
                 self._plans.pop(old).close()
-            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant)
+            if self._wcache is None:
+                self._wcache = WeightCache(self._sd)
+            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
                 # small batches are bound by launch gaps, not by the kernels: replay those plans as one hipGraph
                 use_graph = self.use_graph if self.use_graph is not None else B <= GRAPH_MAX_BATCH
                 p.set_graph(use_graph)
             self._plans[key] = p
+            self._wcache.save()          # no-op unless RTM3D_WEIGHT_CACHE_DIR is set
         return p
 
     def _check_input(self, x):

@@ -115,6 +115,22 @@ def test_paramlist():
     assert q.get_field('class') == [0, 2] and isinstance(q.get_field('t'), np.ndarray) and p.has_field('Ry') and 'Ry' in p.fields()
 
 
+def test_checkpoint_key_alignment_matches_reference():
+    """n2: suffix matching of checkpoint keys against vectors produced by running the reference's own
+    align_and_update_state_dicts (tests/golden/make_golden_checkpoint.py): identical keys, an ImageNet-style backbone
+    file, a DataParallel-wrapped file (nothing matches), deeper nesting, ambiguous suffixes, partial overlap."""
+    import json
+    from rtm3d_amd.check_point import align_and_update_state_dicts
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'checkpoint_align_cases.json')) as f:
+        cases = json.load(f)
+    assert len(cases) >= 6
+    for name, c in cases.items():
+        msd = {k: torch.tensor(-1) for k in c['model_keys']}
+        lsd = {k: torch.tensor(i) for i, k in enumerate(c['loaded_keys'])}
+        align_and_update_state_dicts(msd, lsd)
+        assert [int(msd[k]) for k in c['model_keys']] == c['chosen'], name
+
+
 def test_shard_ranges():
     for total, world in [(256, 8), (10, 3), (5, 8), (32, 1)]:
         r = [rdist.shard_range(total, k, world) for k in range(world)]

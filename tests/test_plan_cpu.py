@@ -52,3 +52,29 @@ def test_weight_packing_roundtrip():
 def test_state_dict_spec_counts():
     assert len(weights.state_dict_spec('DLA-34')) == 321
     assert len(weights.state_dict_spec('RESNET-18')) == 207
+
+
+def test_weight_cache_is_transparent_and_persistent(tmp_path):
+    """n2: BN-folded / composed weights through the WeightCache equal the uncached build bit for bit, a second plan of the
+    same state dict is served from the cache, the on-disk copy is keyed by the state-dict digest."""
+    from rtm3d_amd.weight_cache import WeightCache, state_dict_digest
+    sd = weights.synth_state_dict('RESNET-18', 3, 'trained')
+    ref = plan_mod.build_plan(sd, 'RESNET-18', 2, 64, 128)
+    c = WeightCache(sd, directory=str(tmp_path))
+    a = plan_mod.build_plan(sd, 'RESNET-18', 2, 64, 128, cache=c)
+    miss = c.misses
+    b = plan_mod.build_plan(sd, 'RESNET-18', 1, 96, 160, cache=c)
+    assert c.misses == miss and c.hits >= miss            # nothing folded twice
+    for x, y in zip(ref.ops, a.ops):
+        if x['op'] == 'conv':
+            np.testing.assert_array_equal(x['w'], y['w']); np.testing.assert_array_equal(x['bias'], y['bias'])
+    assert c.save() is not None
+    c2 = WeightCache(sd, directory=str(tmp_path))
+    d = plan_mod.build_plan(sd, 'RESNET-18', 2, 64, 128, cache=c2)
+    assert c2.misses == 0
+    for x, y in zip(ref.ops, d.ops):
+        if x['op'] == 'conv':
+            np.testing.assert_array_equal(x['w'], y['w'])
+    sd2 = dict(sd); sd2['backbone.conv1.weight'] = sd['backbone.conv1.weight'] + 1
+    assert state_dict_digest(sd2) != state_dict_digest(sd)
+    assert WeightCache(sd2, directory=str(tmp_path)).entries == {}
