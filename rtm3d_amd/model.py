@@ -59,7 +59,10 @@ class Model(object):
             raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256, HEADER_NUM_CONV=2')
         # 'rtm3d' (reference main branch) | 'smoke' (head-table variant, SURVEY.md 8 a12: parity unpinned)
         self._head_variant = config.MODEL.get('HEAD_VARIANT', 'rtm3d') if hasattr(config.MODEL, 'get') else getattr(config.MODEL, 'HEAD_VARIANT', 'rtm3d')
-        self._head_channels = [c for _, _, c in head_table(self._head_variant)]
+        # one heat-map channel per class of cfg.DATASET.OBJs (models/nets/header.py:11)
+        objs = getattr(getattr(config, 'DATASET', None), 'OBJs', None)
+        self._num_classes = len(objs) if objs else 3
+        self._head_channels = [c for _, _, c in head_table(self._head_variant, self._num_classes)]
         self.training = True                     # nn.Module default; detect.py:31 calls eval()
         self.export = False
         self._device = None
@@ -68,7 +71,8 @@ class Model(object):
         self._wcache = None
         self.use_graph = None                    # None: automatic (hipGraph replay for batches <= GRAPH_MAX_BATCH)
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
-        self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant)
+        self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant,
+                                    num_classes=self._num_classes)
         self.backbone = _Namespace(self, 'backbone')
         self.kfpn_fusion = _Namespace(self, 'kfpn_fusion')
         self.detect_header = _Namespace(self, 'detect_header')
@@ -78,7 +82,7 @@ class Model(object):
         return OrderedDict(self._sd)
 
     def load_state_dict(self, state_dict, strict=True):
-        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name, self._head_variant))
+        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name, self._head_variant, self._num_classes))
         missing = [k for k in want if k not in state_dict]
         unexpected = [k for k in state_dict if k not in want]
         if strict and (missing or unexpected):
@@ -146,7 +150,8 @@ class Model(object):
                 self._plans.pop(old).close()
             if self._wcache is None:
                 self._wcache = WeightCache(self._sd)
-            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache)
+            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache,
+                                     num_classes=self._num_classes)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
                 # small batches are bound by launch gaps, not by the kernels: replay those plans as one hipGraph
@@ -287,6 +292,9 @@ class Model(object):
         logits = self.forward_logits(x)
         det = self.decode2d(logits)
         dim_ref = dim_ref if dim_ref is not None else self.config.DETECTOR.dim_ref
+        if len(dim_ref) < self._num_classes:
+            # the reference would raise IndexError at dim_ref[cls] (utils/model_utils.py:293); the kernel only clamps
+            raise IndexError('dim_ref has %d rows for %d classes' % (len(dim_ref), self._num_classes))
         if self._head_variant == 'smoke':
             boxes = decode_smoke_slots(det, logits[1], K_per_image, dim_ref, float(self.config.MODEL.DOWN_SAMPLE))
         else:

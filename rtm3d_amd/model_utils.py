@@ -96,6 +96,8 @@ def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_ke
     N = clses.shape[0]
     if N == 0:
         return np.zeros((0, 8)), np.zeros((0,)), np.zeros((0,), np.int32), np.zeros((0,), np.int32)
+    if int(clses.max()) >= len(ref_dim) or int(clses.min()) < 0:
+        raise IndexError('class index %d outside dim_ref with %d rows (utils/model_utils.py:293)' % (int(clses.max()), len(ref_dim)))
     uv = np.ascontiguousarray(np.asarray(bbox3d_projs, np.float32).reshape(N, 16))
     K = np.asarray(K, np.float64)
     Kn = np.ascontiguousarray(np.broadcast_to(K.reshape(-1, 9), (N, 9)) if K.size == 9 else K.reshape(N, 9))

@@ -27,6 +27,8 @@ class Detect3DPipeline(object):
         self.model, self.B, self.dev = model, batch, torch.device(device)
         self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
         dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
+        if len(dim_ref) < getattr(model, '_num_classes', 0):
+            raise IndexError('dim_ref has %d rows for %d classes' % (len(dim_ref), model._num_classes))
         # device-resident constants: a pageable host->device copy inside submit() would block the host
         self.dim_ref = torch.as_tensor(np.asarray(dim_ref, np.float64), device=self.dev)
         self.ref_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=self.dev)

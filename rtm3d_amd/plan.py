@@ -279,19 +279,19 @@ def _build_resnet(P, sd, H, W, depth, feat_out):
             inpl = pl
 
 
-def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None):
+def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None, num_classes=3):
     """state_dict: reference key names -> torch tensors.  H, W multiples of 32.  cache: a WeightCache of this state dict."""
     global _CACHE
     _CACHE = cache
     try:
-        P = _build_plan(state_dict, backbone, B, H, W, head_variant)
+        P = _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes)
     finally:
         _CACHE = None
     P.cache = cache
     return P
 
 
-def _build_plan(state_dict, backbone, B, H, W, head_variant):
+def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3):
     kind, depth = parse_backbone(backbone)
     if H % 32 or W % 32:
         raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
@@ -358,7 +358,7 @@ def _build_plan(state_dict, backbone, B, H, W, head_variant):
     P.softmax_fuse(z0, z, us, name='kfpn_softmax_fuse')
 
     # ---- heads (models/nets/header.py:13-46): the d6 convs of all G branches fused into one 256->G*256 conv
-    heads = head_table(head_variant)
+    heads = head_table(head_variant, num_classes)
     G = len(heads)
     h1 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h1')
     h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2')

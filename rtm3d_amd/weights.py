@@ -31,11 +31,15 @@ HEADS = [('main_kf_header', 'main_kf_head', 3), ('offset_fr_main_header', 'offse
 HEADS_SMOKE = [('main_kf_header', 'main_kf_head', 3), ('regression_header', 'regression_head', 8)]
 
 
-def head_table(variant='rtm3d'):
+def head_table(variant='rtm3d', num_classes=3):
+    """[(branch, last conv, channels)]; the heat-map branch has one channel per class of cfg.DATASET.OBJs
+    (models/nets/header.py:11)."""
+    if not 1 <= int(num_classes) <= 16:
+        raise ValueError('the heat-map head supports 1..16 classes (conv_headout.hip), got %d' % num_classes)
     if variant in (None, 'rtm3d'):
-        return HEADS
+        return [(HEADS[0][0], HEADS[0][1], int(num_classes))] + HEADS[1:]
     if variant == 'smoke':
-        return HEADS_SMOKE
+        return [(HEADS_SMOKE[0][0], HEADS_SMOKE[0][1], int(num_classes))] + HEADS_SMOKE[1:]
     raise ValueError('unknown MODEL.HEAD_VARIANT %r' % (variant,))
 
 
@@ -98,7 +102,7 @@ def _dla_tree_spec(s, p, level, cin, cout, stride, level_root, root_dim=0):
         s.bn(p + '.project.1', cout)
 
 
-def state_dict_spec(backbone, head_variant='rtm3d'):
+def state_dict_spec(backbone, head_variant='rtm3d', num_classes=3):
     """Ordered [(key, shape, kind, meta)] identical to the reference ``state_dict()`` order."""
     kind, depth = parse_backbone(backbone)
     s = _Spec()
@@ -142,7 +146,7 @@ def state_dict_spec(backbone, head_variant='rtm3d'):
         for j in range(i):
             s.deconv('kfpn_fusion.fusion_up%d.%d.conv_tran' % (i + 2, j), oc)
     # models/nets/header.py:13-37
-    for seq, last, cout in head_table(head_variant):
+    for seq, last, cout in head_table(head_variant, num_classes):
         p = 'detect_header.' + seq
         s.conv(p + '.0', oc, oc, 3, bias=True)
         s.bn(p + '.1', oc)
@@ -186,7 +190,7 @@ def _trained_gain(bkind, key):
     return g['conv']
 
 
-def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d', heat_gain=1.0):
+def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d', heat_gain=1.0, num_classes=3):
     """Deterministic synthetic weights (fp32 CPU tensors) under the reference key names.
     ``heat_gain`` scales the last heat-map conv ("trained" style only): > 1 spreads the peak scores over a wider
     range, as a trained detector's are, instead of the narrow band random features give."""
@@ -195,7 +199,7 @@ def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_var
     bkind = parse_backbone(backbone)[0]
     sd = OrderedDict()
     bil = _bilinear_kernel(4)
-    for key, shape, kind, meta in state_dict_spec(backbone, head_variant):
+    for key, shape, kind, meta in state_dict_spec(backbone, head_variant, num_classes):
         if kind == 'conv':
             cout, cin, k, _ = shape
             fan_in, fan_out = cin * k * k, cout * k * k

@@ -574,3 +574,37 @@ def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
     a = mg.forward_logits(xs[1]); b = me.forward_logits(xs[1])      # the first shape was evicted and is rebuilt
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_class_count_follows_dataset_objs(dev):
+    """the heat-map head has len(cfg.DATASET.OBJs) channels (models/nets/header.py:11); a class list of
+    5 runs end to end, and a dim_ref with fewer rows than classes raises like the reference's dim_ref[cls] would."""
+    bb = 'RESNET-18'
+    cfg = rtm3d_amd.kitti_config(bb)
+    cfg.DATASET.OBJs = ['Car', 'Pedestrian', 'Cyclist', 'Van', 'Truck']
+    m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
+    sd = weights.synth_state_dict(bb, 4, 'trained', heat_bias=-2.5, num_classes=5)
+    m.load_state_dict(sd)
+    x = weights.synth_images(2, 64, 128, seed=8)
+    dets, logits = m(x.to(dev))
+    assert logits[0].shape == (2, 5, 16, 32)
+    dref, lref = rtm3d_ref.model_forward(x, sd, bb)
+    for a, b in zip(logits, lref):
+        assert _rel_err(a.cpu().numpy(), b.numpy()) <= LOGIT_RTOL
+    d = m.inference([l.to(dev) for l in lref])                 # decode of the oracle's logits: bit-exact, classes 0..4
+    seen = set()
+    for b in range(2):
+        if dref[0][b] is None:
+            assert d[0][b] is None
+            continue
+        assert torch.equal(d[0][b].cpu(), dref[0][b]) and torch.equal(d[3][b].cpu(), dref[3][b])
+        seen |= set(dref[0][b].tolist())
+    assert max(seen) >= 3
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (2, 1)), device=dev)
+    with pytest.raises(IndexError):
+        m.detect3d(x.to(dev), K)                               # kitti dim_ref has 3 rows
+    with pytest.raises(IndexError):
+        rtm3d_amd.model_utils.optim_decode_bbox3d(np.array([4]), np.zeros((1, 8, 2), np.float32), weights.synth_intrinsics(),
+                                                  cfg.DETECTOR.dim_ref, [0, -0.5, 20])
+    det, boxes, _ = m.detect3d(x.to(dev), K, dim_ref=list(cfg.DETECTOR.dim_ref) + [[2.0, 1.9, 5.0], [3.2, 2.5, 9.0]])
+    assert int(det.n.sum()) == int((boxes.status >= 0).sum())
