@@ -57,6 +57,11 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
                                                            int32_t* __restrict__ status,
                                                            const int32_t* __restrict__ n_per_image, int topk) {
     __shared__ LbWaveMem mems[D3_WPB];
+    // These waves are latency chains that issue an instruction every few hundred cycles; beside the MFMA / DMA
+    // waves of the next batch's convolutions they lose every arbitration at equal priority and the kernel stretches
+    // from 1.3 ms to ~5 ms, into the persistent conv kernels that need whole CUs.  Highest wave priority: the
+    // chains run at their own pace, the co-resident conv waves give up a few issue slots.
+    __builtin_amdgcn_s_setprio(3);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     LbWaveMem& mem = mems[wave];
     const int i = blockIdx.x * D3_WPB + wave;
