@@ -380,14 +380,16 @@ def main():
         # HBM-side traffic of the dominant kernel: PMC counters cannot be collected live inside a timed
         # run, so the per-launch figure comes from the committed rocprofv3 --pmc profile of this workload
         traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_heads.json')) as f:
-                pmc = json.load(f)
-            if B == 32 and (H, W) == (384, 1280) and d['name'] in pmc['kernels']:
-                traffic = pmc['kernels'][d['name']]['hbm_bytes_corrected'] / 1e9
-                traffic_src = 'profiles/r01_pmc_heads.json (GB per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024)'
-        except (OSError, KeyError, ValueError):
-            pass
+        for prof in ('r02_pmc_heads.json', 'r01_pmc_heads.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', prof)) as f:
+                    pmc = json.load(f)
+                if B == 32 and (H, W) == (384, 1280) and d['name'] in pmc['kernels']:
+                    traffic = pmc['kernels'][d['name']]['hbm_bytes_corrected'] / 1e9
+                    traffic_src = 'profiles/%s (GB per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024)' % prof
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (d['kernel'], d['name']),
                 'achieved': d['flops'] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
                 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
