@@ -27,13 +27,14 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
     std::string name;
     double flops, bytes;
     ConvKArgs conv; int groups, bn_tile, epi_nchw, out_slot, ksize;
+    int ticket_slot = -1;           // conv64_halo: index of this op's ticket counter (ctx->tile_ctr + 8 + slot)
     float* stat_out = nullptr;      // softmax partials written by this conv's epilogue (halo kernel), or null
     StemKArgs stem; int stem_cout;
     PoolKArgs pool;
@@ -43,6 +44,7 @@ struct Op {
 
 struct rtm3d_ctx {
     int device;
+    int n_cus = 256;
     std::vector<Tensor> tensors;
     std::vector<void*> blobs;
     std::vector<size_t> blob_bytes;
@@ -52,7 +54,9 @@ struct rtm3d_ctx {
     float* stat_buf = nullptr;
     int stat_chunks = 0, stat_B = 0;
     int stat_tensor[3] = {-1, -1, -1};
-    unsigned int* tile_ctr = nullptr;   // 8 per-XCD ticket counters of the persistent conv kernel (self-resetting)
+    unsigned int* tile_ctr = nullptr;   // [0,8): per-XCD ticket counters of the persistent conv256 kernels (self-resetting);
+                                        // [8, 8+TICKET_SLOTS): one counter per conv64_halo op; all zeroed at the head of every forward
+    int ticket_slots_used = 0;
     // live probe: hipEvent pairs around one op of every replay (bench.py roofline)
     int probe_op = -1;
     std::vector<hipEvent_t> probe_ev;   // 2 * PROBE_RING events
@@ -65,6 +69,16 @@ struct rtm3d_ctx {
     unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0;
 };
 static const int PROBE_RING = 64;
+static const int TICKET_SLOTS = 56;
+static const size_t TILE_CTR_WORDS = 8 + TICKET_SLOTS;
+
+static int ensure_tile_ctr(rtm3d_ctx* ctx) {
+    if (ctx->tile_ctr) return 0;
+    RT_HIP(hipMalloc((void**)&ctx->tile_ctr, TILE_CTR_WORDS * sizeof(unsigned int)));
+    RT_HIP(hipMemset(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int)));
+    ctx->extra.push_back(ctx->tile_ctr);
+    return 0;
+}
 
 extern "C" const char* rtm3d_last_error(void) { return g_err; }
 extern "C" int rtm3d_abi_version(void) { return RTM3D_ABI_VERSION; }
@@ -83,6 +97,7 @@ extern "C" int rtm3d_ctx_create(int device, rtm3d_ctx** out) {
         RT_FAIL("ctx_create: device %d reports %d XCCs / %d CUs; librtm3d_hip is built for the 8-XCD (SPX) MI355X", device, xccs, cus);
     rtm3d_ctx* c = new rtm3d_ctx();
     c->device = device;
+    c->n_cus = cus;
     *out = c;
     return 0;
 }
@@ -236,12 +251,19 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = d->cout * g; }
         op.kind = OP_CONV_MFMA256; op.bn_tile = 256;
         stat_slot = d->softmax_stat_slot;
-        if (!ctx->tile_ctr) {
-            RT_HIP(hipMalloc((void**)&ctx->tile_ctr, 8 * sizeof(unsigned int)));
-            RT_HIP(hipMemset(ctx->tile_ctr, 0, 8 * sizeof(unsigned int)));
-            ctx->extra.push_back(ctx->tile_ctr);
-        }
+        if (ensure_tile_ctr(ctx)) return 1;
         op.name = d->ntaps == 1 ? "conv1x1_mfma256" : (d->ntaps == 4 ? "deconv4x4_phase_mfma256" : "conv3x3_mfma256");
+    } else if (d->kernel == 5) {
+        // 64 -> 64 channel 3x3 halo kernel with the filter bank in registers (conv64_halo.hip)
+        if (d->out_nchw_f32) RT_FAIL("op_conv(conv64): NCHW output unsupported");
+        a.cpt = 1; a.ksteps = 9; a.MT = 0; a.NT = 1;
+        if (!conv64_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv64): needs one 64->64 3x3 stride-1 conv on a map with W %% 32 == 0, H %% 8 == 0");
+        if (wbytes != (size_t)9 * 64 * 64 * sizeof(f16) || bbytes != 64 * sizeof(float)) RT_FAIL("op_conv(conv64): weight/bias blob size mismatch");
+        if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv(conv64): out of ticket counters");
+        if (ensure_tile_ctr(ctx)) return 1;
+        a.g[0].w_off = 0; a.g[0].bias_off = 0;
+        op.kind = OP_CONV64_HALO; op.bn_tile = 64; op.ticket_slot = ctx->ticket_slots_used++;
+        op.name = "conv3x3_c64_halo";
     } else if (d->kernel == 0) {
         const int BN = d->bn_tile;
         if (BN != 16 && BN != 32 && BN != 64 && BN != 128) RT_FAIL("op_conv: bn_tile must be 16/32/64/128");
@@ -414,6 +436,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
             break;
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
+        case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: if (!d_in) break;        // the input tensor was filled by rtm3d_preprocess_batch (out_mode 1)
             e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
@@ -434,7 +457,7 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
     // The persistent convs share 8 self-resetting ticket counters; after an aborted launch (or a replay torn down half
     // way) they would be left non-zero and later launches would silently skip tiles.  Zeroing them in stream order at
     // the head of every replay costs one 32-byte memset node.
-    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, 8 * sizeof(unsigned int), s));
+    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s));
     const int n = (int)ctx->ops.size();
     for (int i = 0; i < n; ++i) {
         const bool probe = probes && (i == ctx->probe_op);
@@ -539,7 +562,7 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) RT_HIP(hipEventCreate(&e));
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, 8 * sizeof(unsigned int), s));
+    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s));
     RT_HIP(hipEventRecord(ev[0], s));
     for (int i = 0; i < n; ++i) {
         if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) return 1;

@@ -457,6 +457,21 @@ def pack_smallc_weights(wt, rows=False):
     return np.ascontiguousarray(out).astype(np.float16).reshape(-1)
 
 
+def conv64_eligible(op):
+    """3x3 / stride 1 / dilation 1 / 64 -> 64 channels on a map that 8 x 32 pixel tiles cover: conv64_halo.hip."""
+    taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    return (op['cin'] == 64 and op['cout'] == 64 and op['groups'] == 1 and op['in_stride'] == 1 and op['out_scale'] == 1
+            and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0)
+
+
+def pack_conv64_weights(wt):
+    """wt: (9, 64, 64) fp32 [tap][cout][cin] -> fp16 [tap][k half][16-channel tile][lane = fk*16 + row][8]: the MFMA A
+    fragments a wave of conv64_halo.hip keeps in registers."""
+    w = wt.reshape(9, 4, 16, 2, 4, 8)                 # tap, ct, row, kk, fk, j
+    w = w.transpose(0, 3, 1, 4, 2, 5)                 # tap, kk, ct, fk, row, j
+    return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
+
+
 def pack_headout_weights(ws, biases):
     """4 x (cout<=16, 256, 3, 3) -> fp16 [head][tap][chunk*2+kk][lane=fk*16+row][8], fp32 bias [head][16]."""
     G = len(ws)
@@ -563,8 +578,13 @@ class RealizedPlan(object):
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
         if variant is None:
-            variant = choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
-        if variant == 2:
+            variant = 5 if conv64_eligible(op) else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
+        if variant == 5:
+            assert conv64_eligible(op), op['name']
+            d.kernel, d.bn_tile = 5, 64
+            d.w_blob = self._blob(self._packed(op, 0, 'c64', 0, lambda: pack_conv64_weights(op['w'][0])))
+            d.bias_blob = self._blob(np.ascontiguousarray(op['bias'][0], np.float32))
+        elif variant == 2:
             packed = [self._packed(op, g, 'mfma', 256, lambda g=g: pack_mfma_weights(op['w'][g], 256)[0]) for g in range(G)]
             d.kernel, d.bn_tile = 2, 256
             d.w_blob, d.bias_blob = self._blob(np.concatenate(packed)), self._blob(np.ascontiguousarray(op['bias'], np.float32).reshape(-1))

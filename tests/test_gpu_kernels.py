@@ -45,6 +45,10 @@ CONV_CASES = [
     (3, 24, 40, 64, 256, 3, 1, 1, True, False, 2, 0),       # mfma256 persistent, ragged M (11.25 tiles), 9 K-tiles
     (2, 12, 20, 256, 256, 1, 1, 1, False, False, 2, 64),    # mfma256 persistent, 1x1: the minimum of 4 K-tiles
     (4, 96, 160, 256, 256, 1, 1, 1, True, False, 2, 0),     # mfma256 persistent, 240 tiles: every workgroup draws several tickets
+    (2, 24, 64, 64, 64, 3, 1, 1, True, True, 5, 64),        # conv64 halo: residual, input slice of a wider tensor, 12 tiles
+    (3, 40, 96, 64, 64, 3, 1, 1, False, False, 5, 0),       # conv64 halo: no ReLU, 45 tiles
+    (1, 8, 32, 64, 64, 3, 1, 1, True, False, 5, 0),         # conv64 halo: a single tile
+    (4, 96, 320, 64, 64, 3, 1, 1, True, True, 5, 0),        # conv64 halo: 480 tiles on 256 workgroups (ticket hand-out)
     (2, 16, 24, 16, 16, 3, 1, 1, True, False, 3, 0),        # smallc 16->16
     (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
     (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
