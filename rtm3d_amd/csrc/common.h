@@ -97,7 +97,21 @@ struct HeadOutArgs {
     int tiles_x, tiles_y;
 };
 
+struct StemFusedArgs {
+    const f16* x4;          // NHWC4 fp16 image tensor (padded, border >= 4)
+    f16* out;               // level0 output tensor
+    const f16* w_base;      // [7 k-steps][64 lanes][8]
+    const f16* w_l0;        // [5 k-steps][64 lanes][8]
+    const float* b_base;    // [16]
+    const float* b_l0;      // [16]
+    int B, H, W;
+    int x_Hp, x_Wp, x_P;
+    int o_Hp, o_Wp, o_C, o_P, o_coff;
+    int tiles_x, tiles_y;
+};
+
 // kernel launchers (each returns hipGetLastError())
+hipError_t launch_stem_fused(const StemFusedArgs& a, hipStream_t s);
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s);

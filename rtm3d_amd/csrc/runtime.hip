@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_STEM_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -40,6 +40,7 @@ struct Op {
     PoolKArgs pool;
     SoftmaxKArgs sm;
     HeadOutArgs ho;
+    StemFusedArgs sf;
 };
 
 struct rtm3d_ctx {
@@ -330,6 +331,37 @@ extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
     return 0;
 }
 
+extern "C" int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor, int out_coff, int w_base_blob, int b_base_blob,
+                                   int w_l0_blob, int b_l0_blob) {
+    Tensor* x = ctx ? get_tensor(ctx, x4_tensor) : nullptr;
+    Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    if (!x || !o) RT_FAIL("op_stem_fused: bad tensors");
+    if (x->C != 4 || x->P < 4) RT_FAIL("op_stem_fused: the input must be the NHWC4 image tensor with a border >= 4");
+    if (o->H != x->H || o->W != x->W || o->B != x->B || out_coff < 0 || out_coff + 16 > o->C || (out_coff % 4)) RT_FAIL("op_stem_fused: output slice mismatch");
+    if (x->H % 16 || x->W % 32) RT_FAIL("op_stem_fused: needs H %% 16 == 0 and W %% 32 == 0 (got %dx%d)", x->H, x->W);
+    size_t wb = 0, bb = 0, wl = 0, bl = 0;
+    const f16* w0 = (const f16*)get_blob(ctx, w_base_blob, &wb);
+    const float* b0 = (const float*)get_blob(ctx, b_base_blob, &bb);
+    const f16* w1 = (const f16*)get_blob(ctx, w_l0_blob, &wl);
+    const float* b1 = (const float*)get_blob(ctx, b_l0_blob, &bl);
+    if (!w0 || !b0 || !w1 || !b1 || wb != 7 * 64 * 8 * sizeof(f16) || wl != 5 * 64 * 8 * sizeof(f16) || bb != 16 * sizeof(float) || bl != 16 * sizeof(float))
+        RT_FAIL("op_stem_fused: weight/bias blob size mismatch");
+    Op op;
+    op.kind = OP_STEM_FUSED; op.name = "stem7x7+conv3x3_fused";
+    StemFusedArgs& a = op.sf;
+    memset(&a, 0, sizeof(a));
+    a.x4 = x->base; a.out = o->base; a.w_base = w0; a.w_l0 = w1; a.b_base = b0; a.b_l0 = b1;
+    a.B = x->B; a.H = x->H; a.W = x->W;
+    a.x_Hp = x->Hp; a.x_Wp = x->Wp; a.x_P = x->P;
+    a.o_Hp = o->Hp; a.o_Wp = o->Wp; a.o_C = o->C; a.o_P = o->P; a.o_coff = out_coff;
+    a.tiles_x = x->W / 32; a.tiles_y = x->H / 16;
+    const double px = (double)x->B * x->H * x->W;
+    op.flops = 2.0 * px * (49.0 * 3 * 16 + 9.0 * 16 * 16);      // the two reference layers (3 real input channels)
+    op.bytes = px * (8.0 + 32.0);                                // NHWC4 image in, 16-channel map out
+    ctx->ops.push_back(op);
+    return 0;
+}
+
 extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     if (!in || !cout4) RT_FAIL("op_headout: bad arguments");
@@ -437,6 +469,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
+        case OP_STEM_FUSED: e = launch_stem_fused(op.sf, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: if (!d_in) break;        // the input tensor was filled by rtm3d_preprocess_batch (out_mode 1)
             e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;

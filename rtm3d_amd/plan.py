@@ -23,6 +23,7 @@ from . import _lib
 from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, head_table
 
 V2_MIN_TILES = 512
+FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
 
@@ -501,9 +502,61 @@ class RealizedPlan(object):
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'], t['pad'], ctypes.byref(tid)), 'tensor_create')
             self.tids.append(tid.value)
         self._stat_slots = self._softmax_stat_producers()
+        self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
+        fused = self._stem_fusion_pairs() if FUSE_STEM else {}
+        skip = set()
         for k, op in enumerate(plan.ops):
             self._k = k
+            if k in skip:
+                continue
+            if k in fused:
+                self._op_stem_fused(op, plan.ops[fused[k]])
+                self.op_names.append(op['name'] + '+' + plan.ops[fused[k]]['name'].split('.')[-1])
+                skip.add(fused[k])
+                continue
             getattr(self, '_op_' + op['op'])(op)
+            self.op_names.append(op['name'])
+
+    def _stem_fusion_pairs(self):
+        """{index of the 7x7 NHWC4 stem conv: index of the 3x3 16->16 conv that is its only consumer}: the pair becomes one
+        launch (conv_stem_fused.hip) and the 16-channel map between them never touches HBM."""
+        P = self.plan
+        pairs = {}
+        for k, a in enumerate(P.ops):
+            if a['op'] != 'conv' or a['cin'] != 4 or a['cout'] != 16 or a['in_stride'] != 1 or len(a['taps'][0]) != 49 or not a['relu']:
+                continue
+            mid = a['out'][0]
+            users = [j for j, o in enumerate(P.ops) if j != k and self._reads(o, mid.tid)]
+            if len(users) != 1:
+                continue
+            b = P.ops[users[0]]
+            taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+            ok = (b['op'] == 'conv' and b['cin'] == 16 and b['cout'] == 16 and b['groups'] == 1 and b['in_stride'] == 1 and b['out_scale'] == 1
+                  and list(b['taps'][0]) == taps3 and b['relu'] and b['res'][0] is None and not b['out_nchw'] and users[0] == k + 1
+                  and b['inp'][0].coff == mid.coff and a['Hm'] % 16 == 0 and a['Wm'] % 32 == 0
+                  and P.tensors[a['inp'][0].tid]['pad'] >= 4)
+            if ok:
+                pairs[k] = users[0]
+        return pairs
+
+    @staticmethod
+    def _reads(op, tid):
+        if op['op'] == 'conv':
+            return any(s.tid == tid for s in op['inp']) or any(r is not None and r.tid == tid for r in op['res'])
+        if op['op'] in ('maxpool', 'headout'):
+            return op['inp'].tid == tid
+        if op['op'] == 'softmax':
+            return op['z_in'].tid == tid or any(u.tid == tid for u in op['us'])
+        return False
+
+    def _op_stem_fused(self, a, b):
+        wb = self._packed(a, 0, 'smallc0', 0, lambda: pack_smallc_weights(a['w'][0], rows=False))
+        wl = self._packed(b, 0, 'smallc0', 0, lambda: pack_smallc_weights(b['w'][0], rows=False))
+        out = b['out'][0]
+        _lib.check(self.lib.rtm3d_op_stem_fused(self.ctx, self.tids[a['inp'][0].tid], self.tids[out.tid], out.coff,
+                                                self._blob(wb), self._blob(np.ascontiguousarray(a['bias'][0], np.float32)),
+                                                self._blob(wl), self._blob(np.ascontiguousarray(b['bias'][0], np.float32))),
+                   'op_stem_fused')
 
     def _softmax_stat_producers(self):
         """{conv op index: slot} for the convolutions whose epilogue can emit the spatial-softmax partials of a
@@ -642,7 +695,7 @@ class RealizedPlan(object):
         for i in range(n.value):
             fl, by, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_char_p()
             _lib.check(self.lib.rtm3d_op_info(self.ctx, i, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(nm)), 'op_info')
-            info.append({'kernel': nm.value.decode(), 'name': self.plan.ops[i]['name'], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
+            info.append({'kernel': nm.value.decode(), 'name': self.op_names[i], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
         return info
 
     def input_tensor(self):
