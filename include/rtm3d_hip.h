@@ -96,12 +96,14 @@ typedef struct rtm3d_conv_desc {
 } rtm3d_conv_desc;
 int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
 
-/* DLA-34 stem, fused (models/nets/dla.py:259-273): base_layer 7x7 3->16 + BN + ReLU and level0 3x3 16->16 + BN + ReLU in one
- * launch; the 16-channel full-resolution intermediate map stays in LDS.  x4_tensor: the NHWC4 image tensor (border >= 4,
- * H % 16 == 0, W % 32 == 0); weights packed as for rtm3d_op_conv kernel = 3 (cin = 4: [7][64][8], cin = 16: [5][64][8]), fp32
- * biases [16] with BN folded.  Same result as the two rtm3d_op_conv launches it replaces up to fp32 summation order.        */
+/* DLA-34 stem, fused (models/nets/dla.py:259-279): base_layer 7x7 3->16 + BN + ReLU, level0 3x3 16->16 + BN + ReLU and - when
+ * w_l1_blob >= 0 - level1 3x3 stride 2 16->32 + BN + ReLU in ONE launch; the 16-channel full-resolution intermediate maps stay
+ * in LDS.  x4_tensor: the NHWC4 image tensor (border >= 4, H % 16 == 0, W % 32 == 0); out_tensor: level0's output (full
+ * resolution, 16 channels at out_coff) or level1's (half resolution, 32 channels).  Weights packed as for rtm3d_op_conv
+ * kernel = 3 (cin = 4: [7][64][8]; cin = 16: [cout/16][5][64][8]), fp32 biases with BN folded.  Same result as the
+ * rtm3d_op_conv launches it replaces up to fp32 summation order.                                                        */
 int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor, int out_coff, int w_base_blob, int b_base_blob,
-                        int w_l0_blob, int b_l0_blob);
+                        int w_l0_blob, int b_l0_blob, int w_l1_blob, int b_l1_blob);
 
 /* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
  * input = the nheads x 256-channel tensor written by the grouped head conv (nheads = 4, or 2 for the

@@ -99,11 +99,13 @@ struct HeadOutArgs {
 
 struct StemFusedArgs {
     const f16* x4;          // NHWC4 fp16 image tensor (padded, border >= 4)
-    f16* out;               // level0 output tensor
+    f16* out;               // level0 output tensor (two-layer form) / level1 output tensor, half resolution (three-layer form)
     const f16* w_base;      // [7 k-steps][64 lanes][8]
     const f16* w_l0;        // [5 k-steps][64 lanes][8]
+    const f16* w_l1;        // [2 channel tiles][5 k-steps][64 lanes][8], or null: two-layer form
     const float* b_base;    // [16]
     const float* b_l0;      // [16]
+    const float* b_l1;      // [32]
     int B, H, W;
     int x_Hp, x_Wp, x_P;
     int o_Hp, o_Wp, o_C, o_P, o_coff;

@@ -1,32 +1,42 @@
-// DLA-34 stem, fused: base_layer (7x7, 3 -> 16, BN, ReLU) + level0 (3x3, 16 -> 16, BN, ReLU) in one kernel
-// (models/nets/dla.py:259-273).  Both layers are HBM-bound on their own (0.22 + 0.25 ms at bs=32: the 16-channel
-// full-resolution map is written once and read back once, 1.0 GB of the 1.6 GB they move); fused, the intermediate map
-// lives in LDS only and the pair moves 0.13 GB in + 0.5 GB out.
+// DLA-34 stem, fused (models/nets/dla.py:259-279):
+//   base_layer (7x7, 3 -> 16, BN, ReLU) + level0 (3x3, 16 -> 16, BN, ReLU) [+ level1 (3x3 stride 2, 16 -> 32, BN, ReLU)]
+// in one kernel.  Each of these layers is HBM-bound on its own (0.22 + 0.25 + 0.18 ms at bs=32: the two 16-channel
+// full-resolution maps are written once and read back once, 2.0 GB of the 2.7 GB the three layers move); fused, the
+// intermediate maps live in LDS only and the kernel moves 0.13 GB in + 0.25 GB out.
 //
-// One 256-thread workgroup per 16 x 32 output tile (several per CU: 28 KB of LDS, few registers - the latency of the
-// loads is covered by occupancy, no DMA ring needed):
-//   1. the (16+8) x (32+10) window of the NHWC4 fp16 image (8 B per pixel) -> LDS;
-//   2. base_layer on the (16+2) x (32+2) halo the 3x3 needs: register-direct MFMA, K-step = one filter row
-//      (7 taps x 4 channels + one zero tap = 32: lane group fk holds the pixels x+2fk, x+2fk+1, which are adjacent in
-//      the NHWC4 window -> one 16-byte operand), bias + ReLU, fp16, -> LDS as [row][column][16 channels];
-//      pixels outside the image are written as ZERO: they are level0's zero padding, not a convolution of padded input;
-//   3. level0 on the 16 x 32 tile from that LDS map: K-step = two taps x 16 channels, bias + ReLU -> global NHWC.
-// Weight fragments (7 + 5 A operands) stay in registers.  Same packing as conv_smallc.hip (cin = 4 / cin = 16 layouts).
+// One 256-thread workgroup per 16 x 32 full-resolution tile (several per CU: ~40 KB of LDS, ~100 registers - the
+// latency of the loads is covered by occupancy, no DMA ring needed):
+//   1. the window of the NHWC4 fp16 image (8 B per pixel) the tile needs -> LDS;
+//   2. base_layer on the halo the next stage needs: register-direct MFMA, K-step = one filter row (7 taps x 4 channels +
+//      one zero tap = 32: lane group fk holds the pixels x+2fk, x+2fk+1, which are adjacent in the NHWC4 window -> one
+//      16-byte operand).  Two 16-column strips are walked DOWN the rows by a wave: the operand of filter row ky at output
+//      row r is the operand of filter row ky - 1 at row r + 1, so one row down keeps 6 of the 7 operands in registers and
+//      reads ONE new 16 bytes.  bias + ReLU, fp16, -> LDS as [row][column][16 channels]; pixels outside the image are
+//      written as ZERO: they are the next layer's zero padding, not a convolution of padded input;
+//   3. level0 from that LDS map: K-step = two taps x 16 channels, bias + ReLU -> global NHWC (two-layer form) or -> LDS
+//      (three-layer form, again with zeros outside the image);
+//   4. (three-layer form) level1 on the 8 x 16 half-resolution tile from the level0 map in LDS -> global NHWC.
+// Weight fragments (7 + 5 + 10 A operands) stay in registers.  Same packing as conv_smallc.hip (cin = 4 / cin = 16 layouts).
 #include "common.h"
 #include "../../include/rtm3d_hip.h"
 
 #define SF_TH 16
 #define SF_TW 32
-#define SF_BH (SF_TH + 2)            // base rows needed
-#define SF_BW (SF_TW + 2)
-#define SF_XH (SF_TH + 8)            // image rows needed (7x7 around every base pixel)
-#define SF_XW (SF_TW + 10)           // + 2: the zero-weighted 8th tap of a filter row still loads a pixel
-#define SF_BPIX (SF_BH * SF_BW)      // 612
-#define SF_BFRAGS ((SF_BPIX + 15) / 16)
 
-__global__ __launch_bounds__(256) void stem_fused_kernel(const StemFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) f16 xt[SF_XH * SF_XW * 4];        // image window, 4 halves per pixel
-    __shared__ __attribute__((aligned(16))) f16 bt[SF_BPIX * 16 + 16 * 16];   // base map (+ slack for the clamped last fragment)
+template <int L1>
+__global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs a) {
+    // regions, in full-resolution pixels relative to the tile origin (y0, x0):
+    //   level0 map: rows -L1 .. 15, columns -L1 .. 31  (the stride-2 3x3 needs one row / column before the tile)
+    //   base map  : one more on every side;  image window: 3 more on every side (+ the zero-weighted 8th tap)
+    constexpr int L0H = SF_TH + L1, L0W = SF_TW + L1;
+    constexpr int BH = L0H + 2, BW = L0W + 2, BO = L1 + 1;           // base map size, offset of its origin (-BO)
+    constexpr int XH = BH + 6, XW = BW + 8, XO = BO + 3;             // window size, offset of its origin (-XO)
+    constexpr int XT_HALVES = XH * XW * 4, L0_HALVES = L1 ? L0H * L0W * 16 : 0;
+    // the window is dead once the base map is complete, the level0 map is born after that: they share storage
+    __shared__ __attribute__((aligned(16))) f16 xt[XT_HALVES > L0_HALVES ? XT_HALVES : L0_HALVES];
+    __shared__ __attribute__((aligned(16))) f16 bt[BH * BW * 16];
+    f16* const l0t = xt;
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fk = lane >> 4;
@@ -35,12 +45,15 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemFusedArgs a) 
     const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
     const int y0 = ty * SF_TH, x0 = tx * SF_TW;
 
-    // ---- 1. image window: rows y0-4 .. y0+19, columns x0-4 .. x0+37 of the padded NHWC4 tensor (8-byte pixels)
+    // ---- 1. image window.  Rows above the padded tensor (first tile row of image 0 in the three-layer form) are clamped
+    // to its first row - a zero border row, and every base pixel that would use them lies outside the image anyway.
     {
-        const f16* src = a.x4 + ((size_t)(n * a.x_Hp + y0 - 4 + a.x_P) * a.x_Wp + (x0 - 4 + a.x_P)) * 4;
-        for (int p = tid; p < SF_XH * SF_XW; p += 256) {
-            const int r = p / SF_XW, c = p - r * SF_XW;
-            *(f16x4*)(xt + p * 4) = *(const f16x4*)(src + ((size_t)r * a.x_Wp + c) * 4);
+        const f16* img = a.x4 + (size_t)n * a.x_Hp * a.x_Wp * 4;
+        for (int p = tid; p < XH * XW; p += 256) {
+            const int r = p / XW, c = p - r * XW;
+            int pr = y0 - XO + r + a.x_P;
+            pr = pr > 0 ? pr : 0;
+            *(f16x4*)(xt + p * 4) = *(const f16x4*)(img + ((ptrdiff_t)pr * a.x_Wp + (x0 - XO + c + a.x_P)) * 4);
         }
     }
     f16x8 wb[7], wl[5];
@@ -51,49 +64,130 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemFusedArgs a) 
     const f32x4 bb = *(const f32x4*)(a.b_base + fk * 4), bl = *(const f32x4*)(a.b_l0 + fk * 4);
     __syncthreads();
 
-    // ---- 2. base_layer on the 18 x 34 halo (612 pixels = 39 fragments of 16, dealt round-robin to the 4 waves)
-    for (int f = wave; f < SF_BFRAGS; f += 4) {
-        int q = f * 16 + frow;
-        q = q < SF_BPIX ? q : SF_BPIX - 1;                  // the last fragment's spare lanes redo pixel 611
-        const int r = q / SF_BW, c = q - r * SF_BW;
-        // operand of filter row ky: pixels (r + ky, c + 2fk), (r + ky, c + 2fk + 1) of the window, 4 channels each
-        const f16* xp = xt + (r * SF_XW + c + 2 * fk) * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const f16x4 lo = *(const f16x4*)(xp + ky * SF_XW * 4), hi = *(const f16x4*)(xp + ky * SF_XW * 4 + 4);
-            const f16x8 xf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky], xf, acc, 0, 0, 0);
-        }
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    // ---- 2. base_layer on the BH x BW halo
+    auto base_store = [&](const f32x4& acc, int r, int c) {
+        const int gy = y0 - BO + r, gx = x0 - BO + c;
         const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         f16x4 h = {(f16)fmaxf(acc[0] + bb[0], 0.f), (f16)fmaxf(acc[1] + bb[1], 0.f), (f16)fmaxf(acc[2] + bb[2], 0.f),
                    (f16)fmaxf(acc[3] + bb[3], 0.f)};
         if (!inside) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        *(f16x4*)(bt + (f * 16 + frow) * 16 + fk * 4) = h;          // slot f*16+frow (= q except in the clamped tail)
+        *(f16x4*)(bt + (r * BW + c) * 16 + fk * 4) = h;
+    };
+    auto window16 = [&](int r, int c) -> f16x8 {           // window pixels (r, c + 2fk), (r, c + 2fk + 1): 16 bytes, 8-byte aligned
+        const f16* xp = xt + (r * XW + c + 2 * fk) * 4;
+        const f16x4 lo = *(const f16x4*)xp, hi = *(const f16x4*)(xp + 4);
+        return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    {
+        // columns 0-31: wave w walks strip w & 1 over rows RA * (w >> 1) .. (the second half is one row shorter when BH is odd)
+        constexpr int RA = (BH + 1) / 2;
+        const int c = (wave & 1) * 16 + frow, rbase = (wave >> 1) * RA;
+        const int nrows = (wave >> 1) ? BH - RA : RA;
+        f16x8 win[7];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) win[ky] = window16(rbase + ky, c);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            if (i < nrows) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky], win[(i + ky) % 7], acc, 0, 0, 0);
+                if (i + 1 < nrows) win[i % 7] = window16(rbase + i + 7, c);     // filter row 6 of the next output row
+                base_store(acc, rbase + i, c);
+            }
+        }
+        // columns 32 .. BW-1 (2 or 3 columns, BH rows): ordinary fragments, one per wave
+        constexpr int RC = BW - 32, RPIX = RC * BH, RFRAGS = (RPIX + 15) / 16;
+        static_assert(RFRAGS <= 4, "remainder fragments must fit the four waves");
+        if (wave < RFRAGS) {
+            int q = wave * 16 + frow;
+            q = q < RPIX ? q : RPIX - 1;                     // the spare lanes of the last fragment redo its last pixel
+            const int r = q / RC, cc = 32 + (q - r * RC);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky], window16(r + ky, cc), acc, 0, 0, 0);
+            base_store(acc, r, cc);
+        }
     }
     __syncthreads();
 
-    // ---- 3. level0 on the 16 x 32 tile: fragment f -> row f >> 1, columns (f & 1) * 16 + frow
-    for (int f = wave; f < SF_TH * 2; f += 4) {
-        const int row = f >> 1, col = (f & 1) * 16 + frow;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- 3. level0 on the L0H x L0W map: pixel q -> row q / L0W, column q % L0W (fragments of 16 consecutive pixels)
+    {
+        constexpr int PIX = L0H * L0W, FR = (PIX + 15) / 16;
+        for (int f = wave; f < FR; f += 4) {
+            int q = f * 16 + frow;
+            const bool live = q < PIX;
+            q = live ? q : PIX - 1;
+            const int row = q / L0W, col = q - row * L0W;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            int t = 2 * s + (fk >> 1);
-            t = t < 9 ? t : 8;                              // the 10th tap has zero weights; any valid address will do
-            const int dy = t / 3, dx = t - dy * 3;
-            const f16x8 xf = *(const f16x8*)(bt + ((row + dy) * SF_BW + col + dx) * 16 + (fk & 1) * 8);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xf, acc, 0, 0, 0);
+            for (int s = 0; s < 5; ++s) {
+                int t = 2 * s + (fk >> 1);
+                t = t < 9 ? t : 8;                          // the 10th tap has zero weights; any valid address will do
+                const int dy = t / 3, dx = t - dy * 3;
+                const f16x8 xf = *(const f16x8*)(bt + ((row + dy) * BW + col + dx) * 16 + (fk & 1) * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xf, acc, 0, 0, 0);
+            }
+            f16x4 h = {(f16)fmaxf(acc[0] + bl[0], 0.f), (f16)fmaxf(acc[1] + bl[1], 0.f), (f16)fmaxf(acc[2] + bl[2], 0.f),
+                       (f16)fmaxf(acc[3] + bl[3], 0.f)};
+            if (L1) {
+                const int gy = y0 - L1 + row, gx = x0 - L1 + col;
+                if (gy < 0 || gx < 0) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};   // level1's zero padding (top / left only)
+                if (live) *(f16x4*)(l0t + q * 16 + fk * 4) = h;
+            } else {
+                f16* op = a.out + ((size_t)(n * a.o_Hp + y0 + row + a.o_P) * a.o_Wp + x0 + col + a.o_P) * a.o_C + a.o_coff + fk * 4;
+                *(f16x4*)op = h;
+            }
         }
-        const f16x4 h = {(f16)fmaxf(acc[0] + bl[0], 0.f), (f16)fmaxf(acc[1] + bl[1], 0.f), (f16)fmaxf(acc[2] + bl[2], 0.f),
-                         (f16)fmaxf(acc[3] + bl[3], 0.f)};
-        f16* op = a.out + ((size_t)(n * a.o_Hp + y0 + row + a.o_P) * a.o_Wp + x0 + col + a.o_P) * a.o_C + a.o_coff + fk * 4;
-        *(f16x4*)op = h;
+    }
+    if (!L1) return;
+    __syncthreads();
+
+    // ---- 4. level1 (3x3, stride 2, 16 -> 32) on the 8 x 16 half-resolution tile: fragment = output row, 16 columns;
+    // output (oy, ox) reads level0-map pixels (2 oy + dy, 2 ox + dx), dy, dx in 0..2 (the map starts one pixel before the tile)
+    {
+        f16x8 w1[2][5];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < 5; ++s) w1[c][s] = *(const f16x8*)(a.w_l1 + ((c * 5 + s) * 64 + lane) * 8);
+        f32x4 b1[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) b1[c] = *(const f32x4*)(a.b_l1 + c * 16 + fk * 4);
+        const int so = (fk & 1) * 16 + (fk >> 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = wave * 2 + j;
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                int t = 2 * s + (fk >> 1);
+                t = t < 9 ? t : 8;
+                const int dy = t / 3, dx = t - dy * 3;
+                const f16x8 xf = *(const f16x8*)(l0t + ((2 * oy + dy) * L0W + 2 * frow + dx) * 16 + (fk & 1) * 8);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[c][s], xf, acc[c], 0, 0, 0);
+            }
+            uint32_t u[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f16x4 h = {(f16)fmaxf(acc[c][0] + b1[c][0], 0.f), (f16)fmaxf(acc[c][1] + b1[c][1], 0.f),
+                                 (f16)fmaxf(acc[c][2] + b1[c][2], 0.f), (f16)fmaxf(acc[c][3] + b1[c][3], 0.f)};
+                __builtin_memcpy(u[c], &h, 8);
+            }
+            // rows (16-lane groups) 1,3 of the c = 0 registers <-> rows 0,2 of the c = 1 registers: 8 consecutive channels per lane
+            const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            f16* op = a.out + ((size_t)(n * a.o_Hp + (y0 >> 1) + oy + a.o_P) * a.o_Wp + (x0 >> 1) + frow + a.o_P) * a.o_C + a.o_coff + so;
+            *(u32x4*)op = o;
+        }
     }
 }
 
 hipError_t launch_stem_fused(const StemFusedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(stem_fused_kernel, dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+    const dim3 grid(a.B * a.tiles_x * a.tiles_y), block(256);
+    if (a.w_l1) hipLaunchKernelGGL(stem_fused_kernel<1>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(stem_fused_kernel<0>, grid, block, 0, s, a);
     return hipGetLastError();
 }

@@ -332,32 +332,38 @@ extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
 }
 
 extern "C" int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor, int out_coff, int w_base_blob, int b_base_blob,
-                                   int w_l0_blob, int b_l0_blob) {
+                                   int w_l0_blob, int b_l0_blob, int w_l1_blob, int b_l1_blob) {
     Tensor* x = ctx ? get_tensor(ctx, x4_tensor) : nullptr;
     Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
     if (!x || !o) RT_FAIL("op_stem_fused: bad tensors");
+    const bool three = w_l1_blob >= 0;
+    const int oc = three ? 32 : 16, sc = three ? 2 : 1;
     if (x->C != 4 || x->P < 4) RT_FAIL("op_stem_fused: the input must be the NHWC4 image tensor with a border >= 4");
-    if (o->H != x->H || o->W != x->W || o->B != x->B || out_coff < 0 || out_coff + 16 > o->C || (out_coff % 4)) RT_FAIL("op_stem_fused: output slice mismatch");
+    if (o->H * sc != x->H || o->W * sc != x->W || o->B != x->B || out_coff < 0 || out_coff + oc > o->C || (out_coff % 8)) RT_FAIL("op_stem_fused: output slice mismatch");
     if (x->H % 16 || x->W % 32) RT_FAIL("op_stem_fused: needs H %% 16 == 0 and W %% 32 == 0 (got %dx%d)", x->H, x->W);
-    size_t wb = 0, bb = 0, wl = 0, bl = 0;
+    size_t wb = 0, bb = 0, wl = 0, bl = 0, w1b = 0, b1b = 0;
     const f16* w0 = (const f16*)get_blob(ctx, w_base_blob, &wb);
     const float* b0 = (const float*)get_blob(ctx, b_base_blob, &bb);
     const f16* w1 = (const f16*)get_blob(ctx, w_l0_blob, &wl);
     const float* b1 = (const float*)get_blob(ctx, b_l0_blob, &bl);
+    const f16* w2 = three ? (const f16*)get_blob(ctx, w_l1_blob, &w1b) : nullptr;
+    const float* b2 = three ? (const float*)get_blob(ctx, b_l1_blob, &b1b) : nullptr;
     if (!w0 || !b0 || !w1 || !b1 || wb != 7 * 64 * 8 * sizeof(f16) || wl != 5 * 64 * 8 * sizeof(f16) || bb != 16 * sizeof(float) || bl != 16 * sizeof(float))
         RT_FAIL("op_stem_fused: weight/bias blob size mismatch");
+    if (three && (!w2 || !b2 || w1b != 2 * 5 * 64 * 8 * sizeof(f16) || b1b != 32 * sizeof(float))) RT_FAIL("op_stem_fused: level1 weight/bias blob size mismatch");
     Op op;
-    op.kind = OP_STEM_FUSED; op.name = "stem7x7+conv3x3_fused";
+    op.kind = OP_STEM_FUSED; op.name = three ? "stem7x7+3x3+3x3s2_fused" : "stem7x7+conv3x3_fused";
     StemFusedArgs& a = op.sf;
     memset(&a, 0, sizeof(a));
-    a.x4 = x->base; a.out = o->base; a.w_base = w0; a.w_l0 = w1; a.b_base = b0; a.b_l0 = b1;
+    a.x4 = x->base; a.out = o->base; a.w_base = w0; a.w_l0 = w1; a.w_l1 = w2; a.b_base = b0; a.b_l0 = b1; a.b_l1 = b2;
     a.B = x->B; a.H = x->H; a.W = x->W;
     a.x_Hp = x->Hp; a.x_Wp = x->Wp; a.x_P = x->P;
     a.o_Hp = o->Hp; a.o_Wp = o->Wp; a.o_C = o->C; a.o_P = o->P; a.o_coff = out_coff;
     a.tiles_x = x->W / 32; a.tiles_y = x->H / 16;
     const double px = (double)x->B * x->H * x->W;
-    op.flops = 2.0 * px * (49.0 * 3 * 16 + 9.0 * 16 * 16);      // the two reference layers (3 real input channels)
-    op.bytes = px * (8.0 + 32.0);                                // NHWC4 image in, 16-channel map out
+    // the reference layers (3 real input channels): 7x7 3->16, 3x3 16->16 at full resolution, 3x3 16->32 at half
+    op.flops = 2.0 * px * (49.0 * 3 * 16 + 9.0 * 16 * 16 + (three ? 9.0 * 16 * 32 / 4 : 0.0));
+    op.bytes = px * (8.0 + (three ? 64.0 / 4 : 32.0));           // NHWC4 image in, 16-channel map (or the 32-channel half-res map) out
     ctx->ops.push_back(op);
     return 0;
 }

@@ -510,33 +510,45 @@ class RealizedPlan(object):
             if k in skip:
                 continue
             if k in fused:
-                self._op_stem_fused(op, plan.ops[fused[k]])
-                self.op_names.append(op['name'] + '+' + plan.ops[fused[k]]['name'].split('.')[-1])
-                skip.add(fused[k])
+                chain = [plan.ops[j] for j in fused[k]]
+                self._op_stem_fused(op, *chain)
+                self.op_names.append('+'.join([op['name']] + [c['name'].split('.')[-1] for c in chain]))
+                skip.update(fused[k])
                 continue
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
 
     def _stem_fusion_pairs(self):
-        """{index of the 7x7 NHWC4 stem conv: index of the 3x3 16->16 conv that is its only consumer}: the pair becomes one
-        launch (conv_stem_fused.hip) and the 16-channel map between them never touches HBM."""
+        """{index of the 7x7 NHWC4 stem conv: [index of the 3x3 16->16 conv that is its only consumer (, index of the 3x3
+        stride-2 16->32 conv that is THAT one's only consumer)]}: the chain becomes one launch (conv_stem_fused.hip) and
+        the 16-channel full-resolution maps between the layers never touch HBM.  FUSE_STEM: True = as deep as possible,
+        2 = the first two layers only (A/B, tests), False = off."""
         P = self.plan
+        taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+
+        def only_user(k, out):
+            users = [j for j, o in enumerate(P.ops) if j != k and self._reads(o, out.tid)]
+            return users[0] if len(users) == 1 and users[0] == k + 1 else None
+
+        def plain3x3(b, src, cin, cout, stride):
+            return (b['op'] == 'conv' and b['cin'] == cin and b['cout'] == cout and b['groups'] == 1 and b['in_stride'] == stride
+                    and b['out_scale'] == 1 and list(b['taps'][0]) == taps3 and b['relu'] and b['res'][0] is None and not b['out_nchw']
+                    and b['inp'][0].tid == src.tid and b['inp'][0].coff == src.coff)
+
         pairs = {}
         for k, a in enumerate(P.ops):
             if a['op'] != 'conv' or a['cin'] != 4 or a['cout'] != 16 or a['in_stride'] != 1 or len(a['taps'][0]) != 49 or not a['relu']:
                 continue
-            mid = a['out'][0]
-            users = [j for j, o in enumerate(P.ops) if j != k and self._reads(o, mid.tid)]
-            if len(users) != 1:
+            if a['Hm'] % 16 or a['Wm'] % 32 or P.tensors[a['inp'][0].tid]['pad'] < 4:
                 continue
-            b = P.ops[users[0]]
-            taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
-            ok = (b['op'] == 'conv' and b['cin'] == 16 and b['cout'] == 16 and b['groups'] == 1 and b['in_stride'] == 1 and b['out_scale'] == 1
-                  and list(b['taps'][0]) == taps3 and b['relu'] and b['res'][0] is None and not b['out_nchw'] and users[0] == k + 1
-                  and b['inp'][0].coff == mid.coff and a['Hm'] % 16 == 0 and a['Wm'] % 32 == 0
-                  and P.tensors[a['inp'][0].tid]['pad'] >= 4)
-            if ok:
-                pairs[k] = users[0]
+            j = only_user(k, a['out'][0])
+            if j is None or not plain3x3(P.ops[j], a['out'][0], 16, 16, 1):
+                continue
+            chain = [j]
+            j2 = only_user(j, P.ops[j]['out'][0])
+            if FUSE_STEM is True and j2 is not None and plain3x3(P.ops[j2], P.ops[j]['out'][0], 16, 32, 2) and P.ops[j2]['out'][0].coff % 8 == 0:
+                chain.append(j2)
+            pairs[k] = chain
         return pairs
 
     @staticmethod
@@ -549,13 +561,18 @@ class RealizedPlan(object):
             return op['z_in'].tid == tid or any(u.tid == tid for u in op['us'])
         return False
 
-    def _op_stem_fused(self, a, b):
+    def _op_stem_fused(self, a, b, c=None):
         wb = self._packed(a, 0, 'smallc0', 0, lambda: pack_smallc_weights(a['w'][0], rows=False))
         wl = self._packed(b, 0, 'smallc0', 0, lambda: pack_smallc_weights(b['w'][0], rows=False))
-        out = b['out'][0]
+        f32 = lambda v: self._blob(np.ascontiguousarray(v, np.float32))
+        last = c if c is not None else b
+        out = last['out'][0]
+        w1, b1 = -1, -1
+        if c is not None:
+            w1 = self._blob(self._packed(c, 0, 'smallc0', 0, lambda: pack_smallc_weights(c['w'][0], rows=False)))
+            b1 = f32(c['bias'][0])
         _lib.check(self.lib.rtm3d_op_stem_fused(self.ctx, self.tids[a['inp'][0].tid], self.tids[out.tid], out.coff,
-                                                self._blob(wb), self._blob(np.ascontiguousarray(a['bias'][0], np.float32)),
-                                                self._blob(wl), self._blob(np.ascontiguousarray(b['bias'][0], np.float32))),
+                                                self._blob(wb), f32(a['bias'][0]), self._blob(wl), f32(b['bias'][0]), w1, b1),
                    'op_stem_fused')
 
     def _softmax_stat_producers(self):

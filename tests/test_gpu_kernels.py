@@ -274,43 +274,52 @@ def test_resnet34_stage_parity():
 
 @pytest.mark.parametrize('shape', [(2, 32, 64), (1, 16, 32), (3, 48, 96)])
 def test_fused_dla_stem_vs_torch(shape):
-    """conv_stem_fused.hip: base_layer 7x7 (3->16) + level0 3x3 (16->16), both + bias + ReLU, in one launch, against
-    plain PyTorch fp32 on fp16-rounded operands (the intermediate map is rounded to fp16 as the unfused path stores it);
-    image borders exercise the zero padding of BOTH layers; also equal to the two-launch path within fp32 summation order."""
+    """conv_stem_fused.hip: base_layer 7x7 (3->16) + level0 3x3 (16->16) [+ level1 3x3 stride 2 (16->32)], each + bias +
+    ReLU, in one launch, against plain PyTorch fp32 on fp16-rounded operands (the intermediate maps are rounded to fp16 as
+    the unfused path stores them); image borders exercise the zero padding of every layer; also equal to the three-launch
+    path within fp32 summation order."""
     B, H, W = shape
     rng = np.random.default_rng(B * 7 + H)
     w0 = (rng.standard_normal((16, 3, 7, 7)) / np.sqrt(3 * 49)).astype(np.float32)
     b0 = rng.standard_normal(16).astype(np.float32) * 0.3
     w1 = (rng.standard_normal((16, 16, 3, 3)) / np.sqrt(16 * 9)).astype(np.float32)
     b1 = rng.standard_normal(16).astype(np.float32) * 0.3
+    w2 = (rng.standard_normal((32, 16, 3, 3)) / np.sqrt(16 * 9)).astype(np.float32)
+    b2 = rng.standard_normal(32).astype(np.float32) * 0.3
     x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
 
     def build():
         P = plan_mod.Plan(B, H, W)
         t_base = P.tensor(H, W, 16, 1)
         P.stem_mfma(t_base, w0, b0, 1, name='base')
-        t_l0 = P.tensor(H, W, 16 + 8, 1)
-        out = P.sub(t_l0, 8, 16)
-        P.conv(t_base, out, w1, b1, relu=True, name='level0')
-        return P, out
+        t_l0 = P.tensor(H, W, 16, 1)
+        P.conv(t_base, t_l0, w1, b1, relu=True, name='level0')
+        t_l1 = P.tensor(H // 2, W // 2, 32 + 8, 1)
+        out = P.sub(t_l1, 8, 32)
+        P.conv(t_l0, out, w2, b2, stride=2, relu=True, name='level1')
+        return P, t_l0, out
 
     res = {}
-    for fuse in (True, False):
+    for fuse, nops in ((True, 2), (2, 3), (False, 4)):
         plan_mod.FUSE_STEM = fuse
         try:
-            P, out = build()
+            P, t_l0, out = build()
             R = plan_mod.RealizedPlan(P, 0)
-            assert (len(R.op_names) == 2) == fuse             # input4 + fused pair | input4 + two convs
+            assert len(R.op_names) == nops, R.op_names         # input4 + (one fused launch | fused pair + level1 | three convs)
             xin = torch.from_numpy(x).cuda()
             outs = [torch.zeros(16, device='cuda') for _ in range(4)]
             R.forward(torch.cuda.current_stream().cuda_stream, xin.data_ptr(), [o.data_ptr() for o in outs])
             torch.cuda.synchronize()
-            res[fuse] = R.download(out)
+            res[fuse] = (R.download(out), R.download(t_l0) if fuse is not True else None)
             R.close()
         finally:
             plan_mod.FUSE_STEM = True
     mid = h(F.conv2d(h(torch.from_numpy(x)), h(torch.from_numpy(w0)), torch.from_numpy(b0), 1, 3).relu())
-    ref = h(F.conv2d(mid, h(torch.from_numpy(w1)), torch.from_numpy(b1), 1, 1).relu()).numpy()
-    for fuse in (True, False):
-        np.testing.assert_allclose(res[fuse], ref, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref).max()))
-    np.testing.assert_allclose(res[True], res[False], rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+    l0 = h(F.conv2d(mid, h(torch.from_numpy(w1)), torch.from_numpy(b1), 1, 1).relu())
+    ref = h(F.conv2d(l0, h(torch.from_numpy(w2)), torch.from_numpy(b2), 2, 1).relu()).numpy()
+    tol = 4e-3 * max(1.0, np.abs(ref).max())
+    for fuse in (True, 2, False):
+        np.testing.assert_allclose(res[fuse][0], ref, rtol=4e-3, atol=tol)
+    for fuse in (2, False):
+        np.testing.assert_allclose(res[fuse][1], l0.numpy(), rtol=3e-3, atol=3e-3 * max(1.0, float(l0.abs().max())))
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=3e-3, atol=tol)
