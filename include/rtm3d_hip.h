@@ -105,6 +105,14 @@ int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* desc);
 int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor, int out_coff, int w_base_blob, int b_base_blob,
                         int w_l0_blob, int b_l0_blob, int w_l1_blob, int b_l1_blob);
 
+/* Entry of a DLA level-1 tree with stride 2 on a 32-channel map (DLA-34 level2, models/nets/dla.py:186-206), three reference ops in
+ * one launch reading the input once: bottom = max_pool2d(x, 2, 2) (never materialised), proj_tensor = BN(conv1x1(bottom)) (the
+ * `project` branch, no ReLU), conv_tensor = ReLU(BN(conv3x3 stride 2 (x))) (tree1.conv1); 32 -> 64 channels each.  Input: 32
+ * channels at in_coff of a tensor with border >= 1, H % 16 == 0, W % 64 == 0.  Weights fp16 [9 taps][4][64 lanes][8] and
+ * [4][64][8] (MFMA A fragments, K = 32), fp32 biases [64] with BN folded.                                                      */
+int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv_tensor, int conv_coff, int proj_tensor, int proj_coff,
+                            int w_conv_blob, int b_conv_blob, int w_proj_blob, int b_proj_blob);
+
 /* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
  * input = the nheads x 256-channel tensor written by the grouped head conv (nheads = 4, or 2 for the
  * "smoke" head table), outputs = rtm3d_forward's first nheads fp32 NCHW logit buffers, cout4[i] channels.  Weights: fp16 [head][tap][8 k-blocks][64 lanes][8]

@@ -47,6 +47,7 @@ SIGNATURES = {
     'rtm3d_op_input_nhwc4': (c_int, [c_void_p, c_int]),
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
     'rtm3d_op_stem_fused': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_op_conv32s2_fused': (c_int, [c_void_p] + [c_int] * 10),
     'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),

@@ -112,7 +112,22 @@ struct StemFusedArgs {
     int tiles_x, tiles_y;
 };
 
+struct Conv32S2Args {
+    const f16* in;          // 32-channel slice of a padded NHWC tensor (border >= 1), full resolution of this op
+    f16* out_conv;          // ReLU(BN(conv3x3 stride 2)), 64 channels, half resolution
+    f16* out_proj;          // BN(conv1x1(maxpool2x2)), 64 channels, half resolution
+    const f16* w_conv;      // [9 taps][4 channel tiles][64 lanes][8]
+    const f16* w_proj;      // [4 channel tiles][64 lanes][8]
+    const float* b_conv;    // [64]
+    const float* b_proj;    // [64]
+    int B, Ho, Wo;
+    int in_Hp, in_Wp, in_C, in_P, in_coff;
+    int oc_Hp, oc_Wp, oc_C, oc_P, oc_coff;
+    int op_Hp, op_Wp, op_C, op_P, op_coff;
+};
+
 // kernel launchers (each returns hipGetLastError())
+hipError_t launch_conv32s2_fused(const Conv32S2Args& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_stem_fused(const StemFusedArgs& a, hipStream_t s);
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);

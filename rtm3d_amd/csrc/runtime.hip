@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_STEM_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -41,6 +41,7 @@ struct Op {
     SoftmaxKArgs sm;
     HeadOutArgs ho;
     StemFusedArgs sf;
+    Conv32S2Args c32;
 };
 
 struct rtm3d_ctx {
@@ -368,6 +369,42 @@ extern "C" int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor
     return 0;
 }
 
+extern "C" int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv_tensor, int conv_coff, int proj_tensor, int proj_coff,
+                                       int w_conv_blob, int b_conv_blob, int w_proj_blob, int b_proj_blob) {
+    Tensor* x = ctx ? get_tensor(ctx, in_tensor) : nullptr;
+    Tensor* oc = ctx ? get_tensor(ctx, conv_tensor) : nullptr;
+    Tensor* op_ = ctx ? get_tensor(ctx, proj_tensor) : nullptr;
+    if (!x || !oc || !op_) RT_FAIL("op_conv32s2_fused: bad tensors");
+    if (x->P < 1 || in_coff < 0 || in_coff + 32 > x->C || (in_coff % 8)) RT_FAIL("op_conv32s2_fused: input slice mismatch (32 channels, border >= 1)");
+    if (x->H % 16 || x->W % 64) RT_FAIL("op_conv32s2_fused: needs H %% 16 == 0 and W %% 64 == 0 (got %dx%d)", x->H, x->W);
+    for (Tensor* o : {oc, op_})
+        if (o->H * 2 != x->H || o->W * 2 != x->W || o->B != x->B) RT_FAIL("op_conv32s2_fused: outputs must have half the input resolution");
+    if (conv_coff < 0 || conv_coff + 64 > oc->C || (conv_coff % 8) || proj_coff < 0 || proj_coff + 64 > op_->C || (proj_coff % 8)) RT_FAIL("op_conv32s2_fused: output slice mismatch");
+    size_t wc = 0, bc = 0, wp = 0, bp = 0;
+    const f16* w0 = (const f16*)get_blob(ctx, w_conv_blob, &wc);
+    const float* b0 = (const float*)get_blob(ctx, b_conv_blob, &bc);
+    const f16* w1 = (const f16*)get_blob(ctx, w_proj_blob, &wp);
+    const float* b1 = (const float*)get_blob(ctx, b_proj_blob, &bp);
+    if (!w0 || !b0 || !w1 || !b1 || wc != 9 * 4 * 64 * 8 * sizeof(f16) || wp != 4 * 64 * 8 * sizeof(f16) || bc != 64 * sizeof(float) || bp != 64 * sizeof(float))
+        RT_FAIL("op_conv32s2_fused: weight/bias blob size mismatch");
+    if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv32s2_fused: out of ticket counters");
+    if (ensure_tile_ctr(ctx)) return 1;
+    Op op;
+    op.kind = OP_CONV32S2_FUSED; op.name = "pool+proj1x1+conv3x3s2_fused"; op.ticket_slot = ctx->ticket_slots_used++;
+    Conv32S2Args& a = op.c32;
+    memset(&a, 0, sizeof(a));
+    a.in = x->base; a.out_conv = oc->base; a.out_proj = op_->base; a.w_conv = w0; a.w_proj = w1; a.b_conv = b0; a.b_proj = b1;
+    a.B = x->B; a.Ho = oc->H; a.Wo = oc->W;
+    a.in_Hp = x->Hp; a.in_Wp = x->Wp; a.in_C = x->C; a.in_P = x->P; a.in_coff = in_coff;
+    a.oc_Hp = oc->Hp; a.oc_Wp = oc->Wp; a.oc_C = oc->C; a.oc_P = oc->P; a.oc_coff = conv_coff;
+    a.op_Hp = op_->Hp; a.op_Wp = op_->Wp; a.op_C = op_->C; a.op_P = op_->P; a.op_coff = proj_coff;
+    const double opx = (double)x->B * oc->H * oc->W;
+    op.flops = 2.0 * opx * (9.0 * 32 * 64 + 32.0 * 64);
+    op.bytes = opx * (4 * 64.0 + 2 * 128.0);                   // 32-channel input once, two 64-channel outputs
+    ctx->ops.push_back(op);
+    return 0;
+}
+
 extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     if (!in || !cout4) RT_FAIL("op_headout: bad arguments");
@@ -476,6 +513,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_STEM_FUSED: e = launch_stem_fused(op.sf, s); break;
+        case OP_CONV32S2_FUSED: e = launch_conv32s2_fused(op.c32, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
         case OP_INPUT4: if (!d_in) break;        // the input tensor was filled by rtm3d_preprocess_batch (out_mode 1)
             e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;

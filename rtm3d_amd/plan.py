@@ -23,6 +23,7 @@ from . import _lib
 from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, head_table
 
 V2_MIN_TILES = 512
+FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 stride-2 conv in one launch (conv32s2_fused.hip)
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
@@ -504,6 +505,7 @@ class RealizedPlan(object):
         self._stat_slots = self._softmax_stat_producers()
         self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
+        entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
         skip = set()
         for k, op in enumerate(plan.ops):
             self._k = k
@@ -514,6 +516,12 @@ class RealizedPlan(object):
                 self._op_stem_fused(op, *chain)
                 self.op_names.append('+'.join([op['name']] + [c['name'].split('.')[-1] for c in chain]))
                 skip.update(fused[k])
+                continue
+            if k in entry:
+                proj, conv = plan.ops[entry[k][0]], plan.ops[entry[k][1]]
+                self._op_conv32s2_fused(op, proj, conv)
+                self.op_names.append(op['name'] + '+project+' + conv['name'].split('.', 2)[-1])
+                skip.update(entry[k])
                 continue
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
@@ -550,6 +558,47 @@ class RealizedPlan(object):
                 chain.append(j2)
             pairs[k] = chain
         return pairs
+
+    def _level_entry_triples(self):
+        """{index of a 2x2/2 max-pool of a 32-channel map: [index of the 1x1 32->64 conv on the pooled map (no ReLU),
+        index of the 3x3 stride-2 32->64 conv (ReLU) on the SAME input]} when the pooled map has no other reader:
+        one launch (conv32s2_fused.hip)."""
+        P = self.plan
+        taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+        out = {}
+        for k, m in enumerate(P.ops[:-2]):
+            if m['op'] != 'maxpool' or m['k'] != 2 or m['stride'] != 2 or m['pad'] != 0 or m['inp'].C != 32:
+                continue
+            pj, cv = P.ops[k + 1], P.ops[k + 2]
+            users = [j for j, o in enumerate(P.ops) if j != k and self._reads(o, m['out'].tid)]
+            Hi, Wi = P.dims(m['inp'])
+            ok = (users == [k + 1] and pj['op'] == 'conv' and cv['op'] == 'conv'
+                  and pj['cin'] == 32 and pj['cout'] == 64 and pj['groups'] == 1 and list(pj['taps'][0]) == [(0, 0)] and pj['in_stride'] == 1
+                  and pj['out_scale'] == 1 and not pj['relu'] and pj['res'][0] is None and not pj['out_nchw']
+                  and pj['inp'][0].tid == m['out'].tid and pj['inp'][0].coff == m['out'].coff
+                  and cv['cin'] == 32 and cv['cout'] == 64 and cv['groups'] == 1 and list(cv['taps'][0]) == taps3 and cv['in_stride'] == 2
+                  and cv['out_scale'] == 1 and cv['relu'] and cv['res'][0] is None and not cv['out_nchw']
+                  and cv['inp'][0].tid == m['inp'].tid and cv['inp'][0].coff == m['inp'].coff
+                  and Hi % 16 == 0 and Wi % 64 == 0 and P.tensors[m['inp'].tid]['pad'] >= 1
+                  and pj['out'][0].coff % 8 == 0 and cv['out'][0].coff % 8 == 0)
+            if ok:
+                out[k] = [k + 1, k + 2]
+        return out
+
+    def _op_conv32s2_fused(self, pool, proj, conv):
+        def pack_conv():
+            w = conv['w'][0].reshape(9, 4, 16, 4, 8)                  # tap, ct, row, fk, j   (cin = fk * 8 + j)
+            return np.ascontiguousarray(w.transpose(0, 1, 3, 2, 4)).astype(np.float16).reshape(-1)     # [tap][ct][fk*16+row][8]
+
+        def pack_proj():
+            w = proj['w'][0].reshape(4, 16, 4, 8)                     # (1 tap) ct, row, fk, j
+            return np.ascontiguousarray(w.transpose(0, 2, 1, 3)).astype(np.float16).reshape(-1)
+        f32 = lambda v: self._blob(np.ascontiguousarray(v, np.float32))
+        x, oc, op = pool['inp'], conv['out'][0], proj['out'][0]
+        _lib.check(self.lib.rtm3d_op_conv32s2_fused(self.ctx, self.tids[x.tid], x.coff, self.tids[oc.tid], oc.coff, self.tids[op.tid], op.coff,
+                                                    self._blob(self._packed(conv, 0, 'c32s2', 0, pack_conv)), f32(conv['bias'][0]),
+                                                    self._blob(self._packed(proj, 0, 'c32p', 0, pack_proj)), f32(proj['bias'][0])),
+                   'op_conv32s2_fused')
 
     @staticmethod
     def _reads(op, tid):

@@ -323,3 +323,46 @@ def test_fused_dla_stem_vs_torch(shape):
     for fuse in (2, False):
         np.testing.assert_allclose(res[fuse][1], l0.numpy(), rtol=3e-3, atol=3e-3 * max(1.0, float(l0.abs().max())))
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=3e-3, atol=tol)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 64), (1, 16, 64), (3, 48, 192)])
+def test_fused_level_entry_vs_torch(shape):
+    """conv32s2_fused.hip: 2x2 max-pool -> 1x1 project (no ReLU) and 3x3 stride-2 conv (ReLU) of one 32-channel map in one
+    launch (DLA level2 entry), against plain PyTorch fp32 on fp16-rounded operands and against the three-launch path."""
+    B, H, W = shape
+    rng = np.random.default_rng(B * 11 + H)
+    wp = (rng.standard_normal((64, 32, 1, 1)) / np.sqrt(32)).astype(np.float32); bp = rng.standard_normal(64).astype(np.float32) * 0.3
+    wc = (rng.standard_normal((64, 32, 3, 3)) / np.sqrt(32 * 9)).astype(np.float32); bc = rng.standard_normal(64).astype(np.float32) * 0.3
+    x = np.abs(rng.standard_normal((B, 32, H, W))).astype(np.float32)          # post-ReLU map (the zero border equals -inf padding of the pool)
+
+    def build():
+        P = plan_mod.Plan(B, H * 2, W * 2)
+        xt = P.tensor(H, W, 32 + 8, 1)
+        xs = P.sub(xt, 8, 32)
+        bottom = P.tensor(H // 2, W // 2, 32, 0)
+        P.maxpool(xs, bottom, 2, 2, 0, name='level2.downsample')
+        resid = P.tensor(H // 2, W // 2, 64, 0)
+        P.conv(bottom, resid, wp, bp, name='level2.project')
+        mt = P.tensor(H // 2, W // 2, 64 + 64, 1)
+        mid = P.sub(mt, 64, 64)
+        P.conv(xs, mid, wc, bc, stride=2, relu=True, name='level2.tree1.conv1')
+        return P, xs, resid, mid
+
+    res = {}
+    for fuse in (True, False):
+        plan_mod.FUSE_LEVEL_ENTRY = fuse
+        try:
+            P, xs, resid, mid = build()
+            R = plan_mod.RealizedPlan(P, 0)
+            assert len(R.op_names) == (1 if fuse else 3), R.op_names
+            R.close()
+            (r, m), _ = _run(P, [(xs, x)], [resid, mid])
+            res[fuse] = (r, m)
+        finally:
+            plan_mod.FUSE_LEVEL_ENTRY = True
+    xh = h(torch.from_numpy(x))
+    ref_r = h(F.conv2d(F.max_pool2d(xh, 2, 2), h(torch.from_numpy(wp)), torch.from_numpy(bp))).numpy()
+    ref_m = h(F.conv2d(xh, h(torch.from_numpy(wc)), torch.from_numpy(bc), 2, 1).relu()).numpy()
+    for fuse in (True, False):
+        np.testing.assert_allclose(res[fuse][0], ref_r, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref_r).max()))
+        np.testing.assert_allclose(res[fuse][1], ref_m, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref_m).max()))
