@@ -199,6 +199,14 @@ int rtm3d_pack_records(void* stream, int B, int topk, const int32_t* d_n, const 
                        const float* d_mproj, const float* d_verts, const float* d_bbox, const double* d_x,
                        const double* d_fun, const int32_t* d_status, double fun_accept, float* d_rec);
 
+/* Box post-processing on the device: for every solved slot (d_status >= 0) the eight corners + the centre of the
+ * box x = [sin, cos, l, h, w, X, Y, Z] projected through K - calc_proj_corners / create_corners / rotation_matrix,
+ * utils/model_utils.py:66-152 - and the bounding rectangle of the eight corners (the 2D box a KITTI label line carries).
+ * d_K: topk > 0 -> one K (9 doubles) per image, slot i belongs to image i / topk; topk == 0 -> one K per slot.
+ * Outputs: d_proj[N][9][2], d_rect[N][4] = (x1, y1, x2, y2) fp64; unsolved slots get zeros.                                     */
+int rtm3d_project_boxes(void* stream, int N, int topk, const double* d_x, const int32_t* d_status, const double* d_K,
+                        double* d_proj, double* d_rect);
+
 /* "smoke" head-table variant (its source is not in the reference snapshot: PARITY
  * UNPINNED, published SMOKE formulation): closed-form box from the 8 regression channels at each key
  * point of the peaks-only decode.  Outputs use the solver's layout x = [sin ry, cos ry, l, h, w, X, Y, Z]. */

@@ -64,6 +64,7 @@ SIGNATURES = {
                                c_void_p, c_void_p]),
     'rtm3d_pack_records': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_double, c_void_p]),
+    'rtm3d_project_boxes': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_decode_smoke': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_preprocess': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

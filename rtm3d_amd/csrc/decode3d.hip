@@ -184,3 +184,68 @@ extern "C" int rtm3d_pack_records(void* stream, int B, int topk, const int32_t* 
     if (e != hipSuccess) { rt_set_error("pack_records launch: %s", hipGetErrorString(e)); return 1; }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Box post-processing on the device: the eight corners + the centre of every solved slot projected
+// into the image, and the corners' bounding rectangle - calc_proj_corners / create_corners / rotation_matrix,
+// utils/model_utils.py:66-152 (|sin|, |cos| < 1e-3 snap to 0; corner order i, j, k in {1, -1} nested, then the centre;
+// divide by z + 1e-6).  One thread per (slot, corner); fp64 like the reference.  Slots with status < 0 get zeros.
+__global__ __launch_bounds__(256) void project_boxes_kernel(int N, int topk, const double* __restrict__ x, const int32_t* __restrict__ status,
+                                                            const double* __restrict__ K, double* __restrict__ proj, double* __restrict__ rect) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int slot = t / 9, c = t - slot * 9;
+    if (slot >= N) return;
+    double u = 0.0, v = 0.0;
+    if (status[slot] >= 0) {
+        const double* xs = x + (size_t)slot * 8;
+        const double* k = K + (size_t)(topk > 0 ? slot / topk : slot) * 9;
+        const double ry = atan2(xs[0], xs[1]);                      // :300
+        double sn = sin(ry), cs = cos(ry);
+        if (fabs(sn) < 1e-3) sn = 0.0;
+        if (fabs(cs) < 1e-3) cs = 0.0;
+        const double dx = xs[2] / 2, dy = xs[3] / 2, dz = xs[4] / 2;  // dimension = (h, w, l) = (x3, x4, x2): half extents (l, h, w) / 2
+        const double sx = c == 8 ? 0.0 : ((c & 4) ? -1.0 : 1.0), sy = c == 8 ? 0.0 : ((c & 2) ? -1.0 : 1.0), sz = c == 8 ? 0.0 : ((c & 1) ? -1.0 : 1.0);
+        // corners = (R diag(dx, dy, dz)) signs + location
+        const double X = (cs * dx) * sx + (sn * dz) * sz + xs[5];
+        const double Y = dy * sy + xs[6];
+        const double Z = (-sn * dx) * sx + (cs * dz) * sz + xs[7];
+        const double pu = k[0] * X + k[1] * Y + k[2] * Z, pv = k[3] * X + k[4] * Y + k[5] * Z, pw = k[6] * X + k[7] * Y + k[8] * Z;
+        u = pu / (pw + 1e-6);
+        v = pv / (pw + 1e-6);
+    }
+    proj[(size_t)t * 2] = u;
+    proj[(size_t)t * 2 + 1] = v;
+    // bounding rectangle of the eight corners: thread c == 0 of a slot recomputes them (the nine threads of a slot may
+    // straddle two waves or blocks; 8 more projections are cheaper than a segmented reduction)
+    if (c == 0) {
+        double x1 = 0.0, y1 = 0.0, x2 = 0.0, y2 = 0.0;
+        if (status[slot] >= 0) {
+            const double* xs = x + (size_t)slot * 8;
+            const double* k = K + (size_t)(topk > 0 ? slot / topk : slot) * 9;
+            const double ry = atan2(xs[0], xs[1]);
+            double sn = sin(ry), cs = cos(ry);
+            if (fabs(sn) < 1e-3) sn = 0.0;
+            if (fabs(cs) < 1e-3) cs = 0.0;
+            const double dx = xs[2] / 2, dy = xs[3] / 2, dz = xs[4] / 2;
+            x1 = y1 = 1e300; x2 = y2 = -1e300;
+            for (int cc = 0; cc < 8; ++cc) {
+                const double sx = (cc & 4) ? -1.0 : 1.0, sy = (cc & 2) ? -1.0 : 1.0, sz = (cc & 1) ? -1.0 : 1.0;
+                const double X = (cs * dx) * sx + (sn * dz) * sz + xs[5], Y = dy * sy + xs[6], Z = (-sn * dx) * sx + (cs * dz) * sz + xs[7];
+                const double pw = k[6] * X + k[7] * Y + k[8] * Z;
+                const double uu = (k[0] * X + k[1] * Y + k[2] * Z) / (pw + 1e-6), vv = (k[3] * X + k[4] * Y + k[5] * Z) / (pw + 1e-6);
+                x1 = fmin(x1, uu); y1 = fmin(y1, vv); x2 = fmax(x2, uu); y2 = fmax(y2, vv);
+            }
+        }
+        rect[(size_t)slot * 4] = x1; rect[(size_t)slot * 4 + 1] = y1; rect[(size_t)slot * 4 + 2] = x2; rect[(size_t)slot * 4 + 3] = y2;
+    }
+}
+
+extern "C" int rtm3d_project_boxes(void* stream, int N, int topk, const double* d_x, const int32_t* d_status, const double* d_K,
+                                   double* d_proj, double* d_rect) {
+    if (N <= 0 || topk < 0) { rt_set_error("project_boxes: bad sizes"); return 1; }
+    if (!d_x || !d_status || !d_K || !d_proj || !d_rect) { rt_set_error("project_boxes: null pointer"); return 1; }
+    hipLaunchKernelGGL(project_boxes_kernel, dim3((N * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, topk, d_x, d_status, d_K, d_proj, d_rect);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("project_boxes launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}

@@ -608,3 +608,32 @@ def test_class_count_follows_dataset_objs(dev):
                                                   cfg.DETECTOR.dim_ref, [0, -0.5, 20])
     det, boxes, _ = m.detect3d(x.to(dev), K, dim_ref=list(cfg.DETECTOR.dim_ref) + [[2.0, 1.9, 5.0], [3.2, 2.5, 9.0]])
     assert int(det.n.sum()) == int((boxes.status >= 0).sum())
+
+
+def test_project_boxes_device_vs_reference_vectors(dev):
+    """n3 on the device: rtm3d_project_boxes against the vectors produced by running the reference's calc_proj_corners
+    (tests/golden/project_cases.npz, incl. yaw values inside the 1e-3 snapping window) and against the host form on the
+    solver's own outputs; fp64, 1e-9 relative (the device's sin/cos/atan2 are not numpy's)."""
+    from rtm3d_amd import kitti_results as kr
+    from rtm3d_amd.model_utils import Boxes3D
+    g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'project_cases.npz'))
+    n = len(g['Ry'])
+    bx = Boxes3D(n, dev)
+    x = np.zeros((n, 8))
+    x[:, 0], x[:, 1] = np.sin(g['Ry']), np.cos(g['Ry'])
+    x[:, 2], x[:, 3], x[:, 4] = g['dimension'][:, 2], g['dimension'][:, 0], g['dimension'][:, 1]
+    x[:, 5:8] = g['location']
+    bx.x.copy_(torch.from_numpy(x).to(dev)); bx.status.fill_(0); bx.status[1] = -1
+    proj, rect = kr.project_boxes_device(bx, np.tile(g['K'].reshape(1, 9), (n, 1)), topk=0)
+    proj, rect = proj.cpu().numpy(), rect.cpu().numpy()
+    for i in range(n):
+        if i == 1:
+            assert not proj[i].any() and not rect[i].any()
+            continue
+        snap = min(abs(np.sin(g['Ry'][i])), abs(np.cos(g['Ry'][i])))
+        if abs(snap - 1e-3) < 1e-9:            # exactly on the snapping threshold: atan2(sin, cos) may land on either side
+            continue
+        np.testing.assert_allclose(proj[i], g['proj'][i], rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(rect[i], np.concatenate([g['proj'][i][:8].min(0), g['proj'][i][:8].max(0)]), rtol=1e-9, atol=1e-7)
+    with pytest.raises(ValueError):
+        kr.project_boxes_device(bx, g['K'].reshape(1, 9), topk=7)
