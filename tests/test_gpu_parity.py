@@ -637,3 +637,44 @@ def test_project_boxes_device_vs_reference_vectors(dev):
         np.testing.assert_allclose(rect[i], np.concatenate([g['proj'][i][:8].min(0), g['proj'][i][:8].max(0)]), rtol=1e-9, atol=1e-7)
     with pytest.raises(ValueError):
         kr.project_boxes_device(bx, g['K'].reshape(1, 9), topk=7)
+
+
+def test_config4_smoke_variant_bs32_full_size(dev):
+    """BASELINE configs[4] at its full size (smoke head table, DLA-34, bs=32, 384x1280; PARITY UNPINNED: the branch's source
+    is not in the reference snapshot).  Size-independent checks: two runs bit-identical, the device decode of the
+    device's own logits equals the oracle's restatement of the decode on those logits (peaks bit-exact, closed-form boxes
+    to fp64 libm accuracy) for a sample of images, slot bookkeeping consistent."""
+    from oracle import smoke_ref
+    from rtm3d_amd.model_utils import decode_smoke_slots
+    bb = 'DLA-34'
+    cfg = rtm3d_amd.kitti_config(bb)
+    cfg.MODEL.HEAD_VARIANT = 'smoke'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-6.0, head_variant='smoke')
+    m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
+    m.load_state_dict(sd)
+    B = 32
+    x = weights.synth_images(B, 384, 1280, seed=1234).to(dev)
+    Knp = np.tile(weights.synth_intrinsics(), (B, 1))
+    K = torch.as_tensor(Knp, device=dev)
+    det, boxes, logits = m.detect3d(x, K)
+    torch.cuda.synchronize()
+    assert len(logits) == 2 and logits[0].shape == (B, 3, 96, 320) and logits[1].shape == (B, 8, 96, 320)
+    n = det.n.cpu().numpy()
+    assert n.sum() > 0 and n.max() <= 100 and int(n.sum()) == int((boxes.status >= 0).sum())
+    keep = [l.clone() for l in logits]
+    x8, cls0 = boxes.x.clone(), det.cls.clone()
+    det2, boxes2, logits2 = m.detect3d(x, K)
+    for a, b in zip(keep, logits2):
+        assert torch.equal(a, b)
+    assert torch.equal(x8, boxes2.x) and torch.equal(cls0, det2.cls)
+    sample = [0, 17, 31]
+    ref = smoke_ref.decode(keep[0][sample].cpu(), keep[1][sample].cpu(), Knp[sample], cfg.DETECTOR.dim_ref, 0.4, 100, 4.0)
+    for j, b in enumerate(sample):
+        if ref[j] is None:
+            assert n[b] == 0
+            continue
+        k = len(ref[j]['cls'])
+        assert n[b] == k
+        np.testing.assert_array_equal(cls0[b * 100:b * 100 + k].cpu().numpy(), ref[j]['cls'])
+        np.testing.assert_array_equal(det.score[b * 100:b * 100 + k].cpu().numpy(), ref[j]['score'])
+        np.testing.assert_allclose(x8[b * 100:b * 100 + k].cpu().numpy(), ref[j]['x8'], rtol=1e-9, atol=1e-9)
