@@ -99,6 +99,7 @@ struct HeadOutArgs {
 
 struct StemFusedArgs {
     const f16* x4;          // NHWC4 fp16 image tensor (padded, border >= 4)
+    const float* x_nchw;    // or (per launch) the caller's fp32 NCHW batch: read directly, x4 unused
     f16* out;               // level0 output tensor (two-layer form) / level1 output tensor, half resolution (three-layer form)
     const f16* w_base;      // [7 k-steps][64 lanes][8]
     const f16* w_l0;        // [5 k-steps][64 lanes][8]

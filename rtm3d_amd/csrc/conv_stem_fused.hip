@@ -45,9 +45,25 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
     const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
     const int y0 = ty * SF_TH, x0 = tx * SF_TW;
 
-    // ---- 1. image window.  Rows above the padded tensor (first tile row of image 0 in the three-layer form) are clamped
-    // to its first row - a zero border row, and every base pixel that would use them lies outside the image anyway.
-    {
+    // ---- 1. image window: straight from the caller's fp32 NCHW batch (a.x_nchw: the NHWC4 conversion pass and its
+    // tensor are skipped; pixels outside the image are the 7x7's zero padding), or from the padded NHWC4 fp16 tensor
+    // (filled by rtm3d_preprocess_batch).  In the latter, rows above the padded tensor (first tile row of image 0 in the
+    // three-layer form) are clamped to its first row - a zero border row, and every base pixel that would use them lies
+    // outside the image anyway.
+    if (a.x_nchw) {
+        const size_t plane = (size_t)a.H * a.W;
+        const float* img = a.x_nchw + (size_t)n * 3 * plane;
+        for (int p = tid; p < XH * XW; p += 256) {
+            const int r = p / XW, c = p - r * XW;
+            const int gy = y0 - XO + r, gx = x0 - XO + c;
+            f16x4 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float* q = img + (size_t)gy * a.W + gx;
+                v = (f16x4){(f16)q[0], (f16)q[plane], (f16)q[2 * plane], (f16)0.f};
+            }
+            *(f16x4*)(xt + p * 4) = v;
+        }
+    } else {
         const f16* img = a.x4 + (size_t)n * a.x_Hp * a.x_Wp * 4;
         for (int p = tid; p < XH * XW; p += 256) {
             const int r = p / XW, c = p - r * XW;

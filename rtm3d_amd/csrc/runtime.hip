@@ -323,7 +323,7 @@ extern "C" int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor) {
     Tensor* o = ctx ? get_tensor(ctx, out_tensor) : nullptr;
     if (!o || o->C != 4) RT_FAIL("op_input_nhwc4: output tensor must have 4 channels");
     Op op;
-    op.kind = OP_INPUT4; op.name = "nchw_f32_to_nhwc4_f16";
+    op.kind = OP_INPUT4; op.name = "nchw_f32_to_nhwc4_f16"; op.stem_cout = 0;
     memset(&op.stem, 0, sizeof(op.stem));
     op.stem.out = o->base; op.stem.B = o->B; op.stem.H = o->H; op.stem.W = o->W;
     op.stem.out_Hp = o->Hp; op.stem.out_Wp = o->Wp; op.stem.out_P = o->P;
@@ -352,6 +352,9 @@ extern "C" int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor
     if (!w0 || !b0 || !w1 || !b1 || wb != 7 * 64 * 8 * sizeof(f16) || wl != 5 * 64 * 8 * sizeof(f16) || bb != 16 * sizeof(float) || bl != 16 * sizeof(float))
         RT_FAIL("op_stem_fused: weight/bias blob size mismatch");
     if (three && (!w2 || !b2 || w1b != 2 * 5 * 64 * 8 * sizeof(f16) || b1b != 32 * sizeof(float))) RT_FAIL("op_stem_fused: level1 weight/bias blob size mismatch");
+    // the conversion pass in front of this op becomes unnecessary: the kernel reads the caller's fp32 batch directly
+    for (auto& prev : ctx->ops)
+        if (prev.kind == OP_INPUT4 && prev.stem.out == x->base) prev.stem_cout = -1;
     Op op;
     op.kind = OP_STEM_FUSED; op.name = three ? "stem7x7+3x3+3x3s2_fused" : "stem7x7+conv3x3_fused";
     StemFusedArgs& a = op.sf;
@@ -512,10 +515,16 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
-        case OP_STEM_FUSED: e = launch_stem_fused(op.sf, s); break;
+        case OP_STEM_FUSED: {
+            StemFusedArgs a = op.sf;
+            a.x_nchw = d_in;                     // null: the NHWC4 tensor was filled by rtm3d_preprocess_batch
+            e = launch_stem_fused(a, s);
+            break;
+        }
         case OP_CONV32S2_FUSED: e = launch_conv32s2_fused(op.c32, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV_SMALLC: e = launch_conv_smallc(op.conv, s); break;
-        case OP_INPUT4: if (!d_in) break;        // the input tensor was filled by rtm3d_preprocess_batch (out_mode 1)
+        case OP_INPUT4: if (!d_in || op.stem_cout == -1) break;   // filled by rtm3d_preprocess_batch (out_mode 1), or its only
+                                                                  // consumer is the fused stem, which reads the fp32 batch itself
             e = launch_nchw_to_nhwc4(d_in, op.stem.out, op.stem.B, op.stem.H, op.stem.W, op.stem.out_Hp, op.stem.out_Wp, op.stem.out_P, s); break;
         case OP_HEADOUT: {
             HeadOutArgs a = op.ho;
