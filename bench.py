@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument('--no-parity', action='store_true', help='skip the 3D-box L-inf check against the CPU oracle')
     ap.add_argument('--parity-images', type=int, default=2)
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
+    ap.add_argument('--depth', type=int, default=0, help='pipeline slots (0: automatic)')
+    ap.add_argument('--side-streams', type=int, default=0, help='decode3d side streams (0: automatic)')
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
@@ -304,7 +306,8 @@ def main():
     topk = int(cfg.DETECTOR.TOPK_CANDIDATES)
 
     from rtm3d_amd.pipeline import Detect3DPipeline
-    pipe = Detect3DPipeline(model, B, dev, gather='always' if use_dist else True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus) if not args.serial else None
+    pipe = Detect3DPipeline(model, B, dev, gather='always' if use_dist else True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus,
+                            depth=args.depth or None, side_streams=args.side_streams or None) if not args.serial else None
     if pipe is not None and use_dist:
         pipe.time_gather = True                 # event pair around the collective on the side stream (diagnostics)
 

@@ -51,6 +51,9 @@ struct ConvKArgs {
     int ntaps;
     int relu, MT, NT;
     int out_H, out_W;             // NCHW fp32 epilogue only
+    float* slab;                  // split-K (conv_mfma_deep_kernel): fp32 partial tiles [split][group][tile][128 x BN], else null
+    int ksplit;                   // number of K ranges (grid.z); 0 / 1 = off
+    int deep;                     // 1: small launch, runs on conv_mfma_deep_kernel (4-slot LDS ring, optional split-K)
     ConvGroupArgs g[RT_MAX_GROUPS];
 };
 
@@ -81,7 +84,8 @@ struct SoftmaxKArgs {
     int u_Hp[3], u_Wp[3], u_C[3], u_P[3];
     float* partial;                // [n_u][B][chunks][C][2] (max, sumexp)
     float* stats;                  // [n_u][B][C][2] (max, 1/sum)
-    int chunks, rows_per_chunk;
+    int chunks, rows_per_chunk;    // reduce pass: one workgroup per (u, image, chunk of rows)
+    int apply_chunks, apply_rows, xsplit, seg_w;   // apply pass: one workgroup per (image, chunk of rows, column segment)
     int partial_chunks;            // > 0: `partial` was written by the producers' epilogues with this many chunks per image
 };
 
@@ -132,6 +136,7 @@ hipError_t launch_conv32s2_fused(const Conv32S2Args& a, int cu_count, unsigned i
 hipError_t launch_stem_fused(const StemFusedArgs& a, hipStream_t s);
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);
 hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi_nchw, hipStream_t s);
+hipError_t launch_conv_mfma_deep(const ConvKArgs& a, int bn_tile, int groups, unsigned int* tile_ctr, hipStream_t s);
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s);
 bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 bool conv64_halo_supported(const ConvKArgs& a, int groups);

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(1024) void softmax_combine_kernel(const SoftmaxKArg
 template <int NU>
 __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a) {
     const int chunk = blockIdx.x, n = blockIdx.y;
+    const int rchunk = chunk / a.xsplit, xseg = chunk - rchunk * a.xsplit;
+    const int x0 = xseg * a.seg_w, x1 = min(x0 + a.seg_w, a.W);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cg = lane & 31, slot = wave * 2 + (lane >> 5);
     float M[NU][8], invS[NU][8];
@@ -126,26 +128,26 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
 #pragma unroll
         for (int e = 0; e < 8; ++e) { M[ui][e] = st[2 * e]; invS[ui][e] = st[2 * e + 1]; }
     }
-    const int y0 = chunk * a.rows_per_chunk;
-    const int y1 = min(y0 + a.rows_per_chunk, a.H);
+    const int y0 = rchunk * a.apply_rows;
+    const int y1 = min(y0 + a.apply_rows, a.H);
     for (int y = y0; y < y1; ++y) {
         const size_t zrow = ((size_t)(n * a.z_Hp + y + a.z_P) * a.z_Wp + a.z_P) * a.z_C + cg * 8;
         const size_t zirow = ((size_t)(n * a.zi_Hp + y + a.zi_P) * a.zi_Wp + a.zi_P) * a.zi_C + cg * 8;
         size_t urow[NU];
 #pragma unroll
         for (int ui = 0; ui < NU; ++ui) urow[ui] = ((size_t)(n * a.u_Hp[ui] + y + a.u_P[ui]) * a.u_Wp[ui] + a.u_P[ui]) * a.u_C[ui] + cg * 8;
-        for (int x = slot; x < a.W; x += 16) {
+        for (int x = x0 + slot; x < x1; x += 16) {
             f16x8 zi[2], v[2][NU];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int xx = x + 8 * k < a.W ? x + 8 * k : x;
+                const int xx = x + 8 * k < x1 ? x + 8 * k : x;
                 zi[k] = *(const f16x8*)(a.z_in + zirow + (size_t)xx * a.zi_C);
 #pragma unroll
                 for (int ui = 0; ui < NU; ++ui) v[k][ui] = *(const f16x8*)(a.u[ui] + urow[ui] + (size_t)xx * a.u_C[ui]);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (x + 8 * k >= a.W) break;
+                if (x + 8 * k >= x1) break;
                 f16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -164,12 +166,12 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
 }
 
 hipError_t launch_softmax_fuse(const SoftmaxKArgs& a, hipStream_t s) {
-    if (a.C != 256 || a.n_u < 1 || a.n_u > 3) return hipErrorInvalidValue;
+    if (a.C != 256 || a.n_u < 1 || a.n_u > 3 || a.xsplit < 1 || a.seg_w < 1 || a.apply_rows < 1) return hipErrorInvalidValue;
     // pass 1 is skipped when the producing convolutions emitted the partials from their epilogues
     if (a.partial_chunks <= 0) hipLaunchKernelGGL(softmax_reduce_kernel, dim3(a.chunks, a.B, a.n_u), dim3(256), 0, s, a);
     hipLaunchKernelGGL(softmax_combine_kernel, dim3(a.B, a.n_u, 1), dim3(1024), 0, s, a);
-    if (a.n_u == 3) hipLaunchKernelGGL(softmax_apply_kernel<3>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
-    else if (a.n_u == 2) hipLaunchKernelGGL(softmax_apply_kernel<2>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(softmax_apply_kernel<1>, dim3(a.chunks, a.B, 1), dim3(256), 0, s, a);
+    if (a.n_u == 3) hipLaunchKernelGGL(softmax_apply_kernel<3>, dim3(a.apply_chunks, a.B, 1), dim3(256), 0, s, a);
+    else if (a.n_u == 2) hipLaunchKernelGGL(softmax_apply_kernel<2>, dim3(a.apply_chunks, a.B, 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(softmax_apply_kernel<1>, dim3(a.apply_chunks, a.B, 1), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -59,6 +59,8 @@ struct rtm3d_ctx {
     unsigned int* tile_ctr = nullptr;   // [0,8): per-XCD ticket counters of the persistent conv256 kernels (self-resetting);
                                         // [8, 8+TICKET_SLOTS): one counter per conv64_halo op; all zeroed at the head of every forward
     int ticket_slots_used = 0;
+    float* slab = nullptr;             // split-K partial sums (shared by all split ops of the plan: they run one after the other)
+    size_t slab_floats = 0;
     // live probe: hipEvent pairs around one op of every replay (bench.py roofline)
     int probe_op = -1;
     std::vector<hipEvent_t> probe_ev;   // 2 * PROBE_RING events
@@ -72,7 +74,8 @@ struct rtm3d_ctx {
 };
 static const int PROBE_RING = 64;
 static const int TICKET_SLOTS = 56;
-static const size_t TILE_CTR_WORDS = 8 + TICKET_SLOTS;
+static const int SPLIT_CTRS = 256;       // per-tile arrival counters of the split-K convolutions (self-resetting, shared by all ops)
+static const size_t TILE_CTR_WORDS = 8 + TICKET_SLOTS + SPLIT_CTRS;
 
 static int ensure_tile_ctr(rtm3d_ctx* ctx) {
     if (ctx->tile_ctr) return 0;
@@ -280,6 +283,37 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         for (int g = 0; g < d->groups; ++g) { a.g[g].w_off = (uint32_t)(per_group * g); a.g[g].bias_off = cout_pad * g; }
         op.kind = OP_CONV_MFMA; op.bn_tile = BN;
         op.name = d->ntaps == 1 ? "conv1x1_mfma" : (d->ntaps == 4 ? "deconv4x4_phase_mfma" : "conv3x3_mfma");
+        // Small launches (no more workgroups than CUs: small batches; bs=1 gives DLA level5 four pixel tiles) run on
+        // conv_mfma_deep_kernel: a 4-slot LDS ring instead of one stage in flight.  When the launch would fill fewer than
+        // half the CUs and has a K loop of >= 8 steps, K is also cut into ranges of >= 4 steps so that the grid about fills
+        // the chip (filling it twice measured slower); the partial tiles go through an fp32 slab and the last workgroup of
+        // a tile to arrive sums them in split order (deterministic).
+        if (!d->out_nchw_f32 && (BN == 64 || BN == 128)) {
+            const long long wgs = (long long)a.MT * a.NT * d->groups;
+            if (wgs <= ctx->n_cus) {
+                a.deep = 1;
+                op.name += "_deep";
+                if (ensure_tile_ctr(ctx)) return 1;
+            }
+            if (a.deep && wgs * 2 <= ctx->n_cus && wgs <= SPLIT_CTRS && a.ksteps >= 8) {
+                int ks = (int)(ctx->n_cus / wgs);
+                if (ks > a.ksteps / 4) ks = a.ksteps / 4;
+                if (ks > 16) ks = 16;
+                if (ks >= 2) {
+                    const size_t need = (size_t)ks * wgs * 128 * BN;
+                    if (need > ctx->slab_floats) {
+                        // (re)allocate; earlier ops keep a stale pointer, so patch every split op recorded so far
+                        float* nslab = nullptr;
+                        RT_HIP(hipMalloc((void**)&nslab, need * sizeof(float)));
+                        ctx->extra.push_back(nslab);
+                        for (auto& prev : ctx->ops) if (prev.kind == OP_CONV_MFMA && prev.conv.ksplit > 1) prev.conv.slab = nslab;
+                        ctx->slab = nslab; ctx->slab_floats = need;
+                    }
+                    a.ksplit = ks; a.slab = ctx->slab;
+                    op.name += "_splitk";
+                }
+            }
+        }
     } else if (d->kernel == 3) {
         if (d->groups != 1 || d->out_nchw_f32 || res) RT_FAIL("op_conv(smallc): groups/NCHW output/residual unsupported");
         if (!conv_smallc_supported(d->cin, d->cout, d->ntaps)) RT_FAIL("op_conv(smallc): no kernel for cin=%d cout=%d ntaps=%d", d->cin, d->cout, d->ntaps);
@@ -473,8 +507,16 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
         if (!u || u->C != 256 || u->H != zi->H || u->W != zi->W || u->B != zi->B) RT_FAIL("op_softmax_fuse: u tensor %d mismatch", i);
         a.u[i] = u->base; a.u_Hp[i] = u->Hp; a.u_Wp[i] = u->Wp; a.u_C[i] = u->C; a.u_P[i] = u->P;
     }
-    a.rows_per_chunk = 2;
+    // one workgroup per (image, chunk): two rows at the batch sizes the path is quoted on.  Small batches: single rows, and
+    // the apply pass (which does not touch the partials) also cuts rows into column segments until the launch has about
+    // two workgroups per CU (bs=1: 48 workgroups -> 384)
+    const bool small = (long long)a.B * ((a.H + 1) / 2) < 2LL * ctx->n_cus;
+    a.rows_per_chunk = small ? 1 : 2;
     a.chunks = (a.H + a.rows_per_chunk - 1) / a.rows_per_chunk;
+    a.apply_rows = a.rows_per_chunk; a.xsplit = 1;
+    while ((long long)a.B * a.chunks * a.xsplit < 2LL * ctx->n_cus && a.xsplit < 8 && a.W / (a.xsplit * 2) >= 32) a.xsplit *= 2;
+    a.seg_w = ((a.W + a.xsplit - 1) / a.xsplit + 7) / 8 * 8;
+    a.apply_chunks = a.chunks * a.xsplit;
     // partials already emitted by the producers' epilogues (rtm3d_conv_desc.softmax_stat_slot)?
     bool emitted = ctx->stat_buf != nullptr && ctx->stat_B == a.B;
     for (int i = 0; i < n_u && emitted; ++i) emitted = ctx->stat_tensor[i] == u_tensors[i];
@@ -510,7 +552,8 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         case OP_CONV_MFMA: {
             ConvKArgs a = op.conv;
             if (op.epi_nchw) a.out = d_out[op.out_slot];
-            e = launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
+            e = a.deep ? launch_conv_mfma_deep(a, op.bn_tile, op.groups, ctx->tile_ctr + 8 + TICKET_SLOTS, s)
+                       : launch_conv_mfma(a, op.bn_tile, op.groups, op.epi_nchw, s);
             break;
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;

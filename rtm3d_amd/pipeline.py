@@ -7,9 +7,15 @@ idle issue slots while batch i+1's backbone is already running:
     main stream : forward(i) -> decode2d(i) -> [event A_i] ............. forward(i+1) -> ...
     side stream :                               wait A_i -> decode3d(i) -> pack -> all-gather(i) -> [event B_i]
 
-Outputs are double-buffered (slot i % 2); the main stream waits for B_{i-2} before decode2d
-overwrites slot i % 2.  No host synchronisation inside; `results(i)` hands out the records of a
+Outputs are multi-buffered (slot i % depth); the main stream waits for B_{i-depth} before decode2d
+overwrites slot i % depth.  No host synchronisation inside; `results(i)` hands out the records of a
 finished step after waiting on B_i.
+
+Small batches (<= SMALL_BATCH images): the solve of a handful of objects is ONE wavefront per object walking a serial
+fp64 iteration (measured 1.46 ms for 15 objects at bs=1, profiles/r02_small_batch.txt) - longer than the whole network
+(1.27 ms).  A single side stream would serialise the decodes of consecutive steps and bound the step at that latency, so
+small batches use depth 3 and one side stream per slot: decode3d(i) and decode3d(i+1) overlap each other and the step
+is bound by the network again.
 """
 import os
 
@@ -21,9 +27,12 @@ from .model_utils import Boxes3D, decode3d_slots
 from . import distributed as rdist
 
 
+SMALL_BATCH = 2      # batches whose 3D decode (a serial fp64 iteration per object, ~1.5 ms) outlasts the network
+
+
 class Detect3DPipeline(object):
-    def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=2, decode3d=True,
-                 side_cus=0):
+    def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=None, decode3d=True,
+                 side_cus=0, side_streams=None):
         self.model, self.B, self.dev = model, batch, torch.device(device)
         self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
         dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
@@ -34,9 +43,14 @@ class Detect3DPipeline(object):
         self.ref_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=self.dev)
         self.gather = gather
         self.decode3d = decode3d          # False: diagnostic only (measures what the 3D decode costs the pipeline)
+        small = batch <= SMALL_BATCH
+        depth = depth if depth else (3 if small else 2)
         self.depth = depth
+        n_side = side_streams if side_streams else (depth if small else 1)
+        if not 1 <= n_side <= depth:
+            raise ValueError('side_streams must be in 1..depth (%d), got %d' % (depth, n_side))
         with torch.cuda.device(self.dev):
-            self.side = self._make_side_stream(side_cus)
+            self.sides = [self._make_side_stream(side_cus, n_side) for _ in range(n_side)]
             self.det = [Detections(batch, self.topk, self.dev) for _ in range(depth)]
             self.boxes = [Boxes3D(batch * self.topk, self.dev) for _ in range(depth)]
             self.ev_a = [torch.cuda.Event() for _ in range(depth)]
@@ -49,7 +63,7 @@ class Detect3DPipeline(object):
         self.rec = [None] * depth
         self.count = 0
 
-    def _make_side_stream(self, side_cus):
+    def _make_side_stream(self, side_cus, n_side=1):
         """Side stream confined to `side_cus` CUs: the decode's long-lived waves stay off the CUs that the
         256x256-tile convolutions of the next batch need whole (they cannot co-reside: VGPR/LDS)."""
         if side_cus and side_cus > 0:
@@ -60,7 +74,12 @@ class Detect3DPipeline(object):
             _lib.check(lib.rtm3d_stream_create_cumask(self.dev.index, int(side_cus), ctypes.byref(h)), 'stream_create_cumask')
             self._side_handle = h
             return torch.cuda.ExternalStream(h.value, device=self.dev)
-        return torch.cuda.Stream(device=self.dev, priority=int(os.environ.get('RTM3D_SIDE_PRIO', '-1')))
+        # one side stream: high priority, so the decode's few waves are not queued behind the next batch's thousands of
+        # workgroups.  Several side streams (small batches): default priority - three high-priority streams next to a graph
+        # replay measured 4.3 ms per bs=1 step against 1.36 ms at priority 0 (profiles/r02_small_batch.txt)
+        prio = os.environ.get('RTM3D_SIDE_PRIO')
+        prio = int(prio) if prio is not None else (-1 if n_side == 1 else 0)
+        return torch.cuda.Stream(device=self.dev, priority=prio)
 
     def submit(self, x, K_per_image):
         """Enqueue one batch; returns its step index.  Asynchronous."""
@@ -80,19 +99,20 @@ class Detect3DPipeline(object):
         logits = self.model.forward_logits(x)
         self.model.decode2d(logits, out=self.det[s])
         self.ev_a[s].record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_a[s])
+        side = self.sides[s % len(self.sides)]
+        with torch.cuda.stream(side):
+            side.wait_event(self.ev_a[s])
             if self.decode3d:
                 decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
             d = self.det[s]
             rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk,
                                      self.boxes[s] if self.decode3d else None, out=self.rec_local[s])
             if self.time_gather:
-                self.ev_g0[s].record(self.side)
+                self.ev_g0[s].record(side)
             self.rec[s] = rdist.all_gather_records(rec, always=self.gather == 'always') if self.gather else rec
             if self.time_gather:
-                self.ev_g1[s].record(self.side)
-            self.ev_b[s].record(self.side)
+                self.ev_g1[s].record(side)
+            self.ev_b[s].record(side)
         self.count += 1
         return i
 
@@ -109,5 +129,6 @@ class Detect3DPipeline(object):
         return self.ev_g0[s].elapsed_time(self.ev_g1[s]) * 1e3
 
     def drain(self):
-        self.side.synchronize()
+        for side in self.sides:
+            side.synchronize()
         torch.cuda.current_stream(self.dev).synchronize()

@@ -764,6 +764,15 @@ class RealizedPlan(object):
             info.append({'kernel': nm.value.decode(), 'name': self.op_names[i], 'ms': float(ms[i]), 'flops': fl.value, 'bytes': by.value})
         return info
 
+    def kernel_names(self):
+        """Kernel name of every recorded runtime op (rtm3d_op_info), in launch order."""
+        names = []
+        for i in range(len(self.op_names)):
+            fl, by, nm = ctypes.c_double(), ctypes.c_double(), ctypes.c_char_p()
+            _lib.check(self.lib.rtm3d_op_info(self.ctx, i, ctypes.byref(fl), ctypes.byref(by), ctypes.byref(nm)), 'op_info')
+            names.append(nm.value.decode())
+        return names
+
     def input_tensor(self):
         """(device address, border) of the fp16 NHWC4 tensor the stem reads (rtm3d_input_tensor)."""
         base, B, H, W, P = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

