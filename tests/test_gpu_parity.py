@@ -475,18 +475,20 @@ def test_config2_dla34_bs32_full_size_properties(dev):
             assert np.abs(key1[kk] - v).max() <= 0.25
 
 
-def test_two_stream_pipeline_equals_serial_path(dev):
+@pytest.mark.parametrize('B', [3, 1])
+def test_two_stream_pipeline_equals_serial_path(dev, B):
     """The bench path (forward ∥ decode3d on two streams, double-buffered slots) returns exactly the records
-    of the serial path, for a sequence of different batches (exercises slot reuse and event ordering)."""
+    of the serial path, for a sequence of different batches (exercises slot reuse and event ordering).  B = 1 takes the
+    small-batch configuration: hipGraph replay, three slots, one decode stream per slot."""
     from rtm3d_amd.pipeline import Detect3DPipeline
     from rtm3d_amd import distributed as rdist
     bb = 'RESNET-18'
     sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5)
     m = make_model(bb, sd)
-    B = 3
     K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), device=dev)
-    xs = [weights.synth_images(B, 64, 128, seed=100 + 7 * i).to(dev) for i in range(5)]
+    xs = [weights.synth_images(B, 64, 128, seed=100 + 7 * i).to(dev) for i in range(7)]
     pipe = Detect3DPipeline(m, B, dev, gather=True)
+    assert (pipe.depth, len(pipe.sides)) == ((3, 3) if B == 1 else (2, 1))
     ids = [pipe.submit(x, K) for x in xs[:2]]
     got = {ids[0]: pipe.results(ids[0]).clone()}            # read slot 0 before it is reused
     for x in xs[2:]:
