@@ -101,18 +101,36 @@ struct LbWork {
 #define WN_(i, j) w->wn[((j)-1) * LB_M2 + (i)-1]
 #define WN1_(i, j) w->wn1[((j)-1) * LB_M2 + (i)-1]
 
+// Reciprocal square root to ~1 ulp: hardware estimate (v_rsq_f64) on the device, 1/sqrt on the host, then two Newton
+// steps y += y * (1/2 - (x/2) y^2) in fused arithmetic.  ONE long dependent fp64 operation per Cholesky pivot instead of a
+// square root followed by a division (the solver is a serial chain of such pivots: DESIGN.md section 3, decode3d).
+LB_HD static inline double lb_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+#else
+    double y = 1.0 / sqrt(x);
+#endif
+    const double h = 0.5 * x;
+    double e = fma(-(h * y), y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-(h * y), y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
 // Cholesky A = U'U of the leading n x n block of a column-major matrix with leading dimension
 // lda (upper triangle in/out).  Unblocked left-looking form: u_jj = sqrt(a_jj - u_j'u_j),
-// row j scaled by the reciprocal.  Returns 0 or the failing 1-based column.
+// row j scaled by the reciprocal.  THE DIAGONAL OF THE RESULT HOLDS 1 / u_jj: its only readers are the triangular solves
+// below, which multiply by it (a division per substitution step was 30 % of an L-BFGS-B iteration on the GPU).
+// Returns 0 or the failing 1-based column.
 LB_HD static inline int lb_potrf(double* a, int lda, int n) {
     for (int j = 0; j < n; ++j) {
         double s = 0.0;
         for (int k = 0; k < j; ++k) s += a[j * lda + k] * a[j * lda + k];
-        double ajj = a[j * lda + j] - s;
+        const double ajj = a[j * lda + j] - s;
         if (!(ajj > 0.0)) { a[j * lda + j] = ajj; return j + 1; }
-        ajj = sqrt(ajj);
-        a[j * lda + j] = ajj;
-        const double rinv = 1.0 / ajj;
+        const double rinv = lb_rsqrt(ajj);
+        a[j * lda + j] = rinv;
         for (int i = j + 1; i < n; ++i) {
             double dot = 0.0;
             for (int k = 0; k < j; ++k) dot += a[j * lda + k] * a[i * lda + k];
@@ -121,20 +139,20 @@ LB_HD static inline int lb_potrf(double* a, int lda, int n) {
     }
     return 0;
 }
-// solve U' x = b (forward) and U x = b (backward), U upper triangular, in place.
+// solve U' x = b (forward) and U x = b (backward), U upper triangular with RECIPROCAL diagonal (lb_potrf), in place.
 LB_HD static inline int lb_trsv_ut(const double* a, int lda, int n, double* b) {
     for (int j = 0; j < n; ++j) {
         if (a[j * lda + j] == 0.0) return j + 1;
         double dot = 0.0;
         for (int k = 0; k < j; ++k) dot += a[j * lda + k] * b[k];
-        b[j] = (b[j] - dot) / a[j * lda + j];
+        b[j] = (b[j] - dot) * a[j * lda + j];
     }
     return 0;
 }
 LB_HD static inline int lb_trsv_un(const double* a, int lda, int n, double* b) {
     for (int j = n - 1; j >= 0; --j) {
         if (a[j * lda + j] == 0.0) return j + 1;
-        b[j] = b[j] / a[j * lda + j];
+        b[j] = b[j] * a[j * lda + j];
         const double tmp = -b[j];
         for (int k = 0; k < j; ++k) b[k] += tmp * a[j * lda + k];
     }
@@ -375,13 +393,13 @@ LB_HD static inline int lb_subsm(LbWork* w, double theta, int col, int head) {
     for (int i = 0; i < col; ++i) wv[i] = -wv[i];
     if (lb_trsv_un(w->wn, LB_M2, col2, wv) != 0) return 1;
     pointr = head;
+    const double rt = 1.0 / theta;       // (multiplied in below instead of col divisions per component)
     for (int jy = 1; jy <= col; ++jy) {
         const int js = col + jy;
         for (int i = 1; i <= n; ++i)
-            d[i - 1] = d[i - 1] + WY_(i, pointr) * wv[jy - 1] / theta + WS_(i, pointr) * wv[js - 1];
+            d[i - 1] = d[i - 1] + WY_(i, pointr) * wv[jy - 1] * rt + WS_(i, pointr) * wv[js - 1];
         pointr = pointr % m + 1;
     }
-    const double rt = 1.0 / theta;
     for (int i = 0; i < n; ++i) d[i] = rt * d[i];
     for (int i = 0; i < n; ++i) w->z[i] = w->z[i] + d[i];
     return 0;
@@ -418,12 +436,14 @@ LB_HD static inline void lb_matupd(LbWork* w, int* itail, int iupdat, int* col, 
 }
 
 LB_HD static inline int lb_formt(LbWork* w, int col, double theta) {
+    double rsy[LB_M];                    // 1 / SY(k, k): one division per column instead of one per term
+    for (int k = 1; k <= col; ++k) rsy[k - 1] = 1.0 / SY_(k, k);
     for (int j = 1; j <= col; ++j) WT_(1, j) = theta * SS_(1, j);
     for (int i = 2; i <= col; ++i)
         for (int j = i; j <= col; ++j) {
             const int k1 = (i < j ? i : j) - 1;
             double ddum = 0.0;
-            for (int k = 1; k <= k1; ++k) ddum = ddum + SY_(i, k) * SY_(j, k) / SY_(k, k);
+            for (int k = 1; k <= k1; ++k) ddum = ddum + SY_(i, k) * SY_(j, k) * rsy[k - 1];
             WT_(i, j) = ddum + theta * SS_(i, j);
         }
     return lb_potrf(w->wt, LB_M, col) != 0 ? -3 : 0;

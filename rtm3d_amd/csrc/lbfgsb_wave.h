@@ -100,10 +100,14 @@ __device__ static inline double lbw_dot8(const double* a, const double* b) {
     return s;
 }
 
-// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block (n <= LB_M), in place.
+// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block (n <= LB_M), in place; the diagonal of
+// the result holds 1 / u_jj (lb_potrf).
 // One template instance per pivot: the inner trip counts are compile-time constants, so all LDS
 // operands of a step are issued together (a rolled loop pays one LDS round trip per term).
 // Every sum still runs in index order.
+// (Measured alternative, not kept: columns and running dot sums in registers for the whole factorisation, row entries
+// by v_readlane - no LDS round trip per pivot, but the 45 broadcast-multiply-add updates of a 10 x 10 block sit in the
+// same in-order instruction stream as the pivot chain: +1.2k cycles per factorisation.)
 template <int J>
 __device__ static inline int lbw_potrf_step(double* a, int lda, int n, int lane) {
     const int i = J + 1 + lane;
@@ -116,14 +120,13 @@ __device__ static inline int lbw_potrf_step(double* a, int lda, int n, int lane)
     double s = 0.0, dot = 0.0;
 #pragma unroll
     for (int k = 0; k < J; ++k) { s += cj[k] * cj[k]; dot += cj[k] * ci[k]; }
-    double ajj = ajj0 - s;
+    const double ajj = ajj0 - s;
     if (!(ajj > 0.0)) return J + 1;                     // uniform
-    ajj = sqrt(ajj);
-    const double rinv = 1.0 / ajj;
+    const double rinv = lb_rsqrt(ajj);                  // the diagonal keeps 1 / u_jj (lb_potrf)
     const double v = (aij - dot) * rinv;
     WSYNC();                                            // everyone has read column J / a(J,J)
     if (act) a[i * lda + J] = v;
-    if (lane == 0) a[J * lda + J] = ajj;
+    if (lane == 0) a[J * lda + J] = rinv;
     WSYNC();
     return 0;
 }
@@ -134,43 +137,55 @@ __device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
     return 0;
 }
 
-// U' x = b, single right-hand side in LDS (length n <= 64): lane j owns b[j] and its partial sum; the
-// pivot value travels by v_readlane (no LDS write/read pair, no barrier inside the loop).
+// U' x = b, single right-hand side in LDS (n <= LB_M2): lane j owns b[j], its partial sum and COLUMN j of U in registers
+// (all operands of the solve are fetched by one batch of LDS reads: a substitution step that waits for its own LDS
+// read costs ~330 cycles, one that only passes the pivot value by v_readlane ~90); lane k also holds the k-th
+// (reciprocal) diagonal entry.  The diagonal is never zero after a successful lb_potrf; a zero anywhere is reported before
+// the first step (the callers only test for != 0).
 __device__ static inline int lbw_trsv_ut(const double* a, int lda, int n, double* b, double* bc, int lane) {
     (void)bc;
     const bool act = lane < n;
     const int col = (act ? lane : 0) * lda;
-    double dot = 0.0;
+    double cv[LB_M2];
+#pragma unroll
+    for (int k = 0; k < LB_M2; ++k) cv[k] = a[col + (k < n ? k : 0)];
+    const double dg = a[col + (act ? lane : 0)];
     double bj = act ? b[lane] : 0.0;
-    double anext = a[col], dnext = a[0];
-    for (int k = 0; k < n; ++k) {
-        const double akk = dnext, ak = anext;
-        if (k + 1 < n) { anext = a[col + k + 1]; dnext = a[(k + 1) * lda + k + 1]; }   // prefetch next step's operands
-        if (akk == 0.0) return k + 1;
-        const double mine = (bj - dot) / akk;
-        if (lane == k) bj = mine;
-        const double bk = lbw_bcast(bj, k);
-        if (lane > k && act) dot += ak * bk;
+    if (__any(act && dg == 0.0)) return 1;
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < LB_M2; ++k) {
+        if (k < n) {
+            // every lane forms (b - dot) / u_ll with its OWN diagonal entry; lane k's is x_k (its dot is complete at step k)
+            const double mine = (bj - dot) * dg;
+            const double bk = lbw_bcast(mine, k);
+            if (lane == k) bj = mine;
+            if (lane > k && act) dot += cv[k] * bk;
+        }
     }
     if (act) b[lane] = bj;
     WSYNC();
     return 0;
 }
-// U x = b (column-oriented back substitution, same update order as the scalar version)
+// U x = b (column-oriented back substitution, same update order as the scalar version): lane i owns b[i] and ROW i of U
 __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double* b, double* bc, int lane) {
     (void)bc;
     const bool act = lane < n;
     const int row = act ? lane : 0;
+    double rv[LB_M2];
+#pragma unroll
+    for (int j = 0; j < LB_M2; ++j) rv[j] = a[(j < n ? j : 0) * lda + row];
+    const double dg = a[row * lda + row];
     double bk = act ? b[lane] : 0.0;
-    double anext = a[(n - 1) * lda + row], dnext = a[(n - 1) * lda + n - 1];
-    for (int j = n - 1; j >= 0; --j) {
-        const double ajj = dnext, aj = anext;
-        if (j > 0) { anext = a[(j - 1) * lda + row]; dnext = a[(j - 1) * lda + j - 1]; }
-        if (ajj == 0.0) return j + 1;
-        const double mine = bk / ajj;
-        if (lane == j) bk = mine;
-        const double tmp = -lbw_bcast(bk, j);
-        if (lane < j) bk += tmp * aj;
+    if (__any(act && dg == 0.0)) return 1;
+#pragma unroll
+    for (int j = LB_M2 - 1; j >= 0; --j) {
+        if (j < n) {
+            const double mine = bk * dg;                     // own (reciprocal) diagonal entry: lane j's is x_j
+            const double tmp = -lbw_bcast(mine, j);
+            if (lane == j) bk = mine;
+            if (lane < j) bk += tmp * rv[j];
+        }
     }
     if (act) b[lane] = bk;
     WSYNC();
@@ -185,7 +200,7 @@ __device__ static inline void lbw_rhs_step(const double* u, double* bv, int* bad
     double dot = 0.0;
 #pragma unroll
     for (int k = 0; k < J; ++k) dot += u[J * LB_M2 + k] * bv[k];
-    bv[J] = (bv[J] - dot) / ajj;
+    bv[J] = (bv[J] - dot) * ajj;                         // ajj = 1 / u_jj
 }
 #define LBW_RSTEP(J) if (n > J && !bad) lbw_rhs_step<J>(u, bv, &bad);
 __device__ static inline int lbw_rhs_solve(const double* u, double* b, int n) {
@@ -273,8 +288,12 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         const int i = lane - j * (j + 1) / 2;
         if (j < col) {
             const int is = col + 1 + i, js = col + 1 + j;
+            double pa[LB_M], pb[LB_M];
+#pragma unroll
+            for (int k = 1; k <= LB_M; ++k) { const int kk = k <= col ? k : 1; pa[k - 1] = VWN_(kk, is); pb[k - 1] = VWN_(kk, js); }
             double dot = 0.0;
-            for (int k = 1; k <= col; ++k) dot += VWN_(k, is) * VWN_(k, js);
+#pragma unroll
+            for (int k = 1; k <= LB_M; ++k) if (k <= col) dot += pa[k - 1] * pb[k - 1];
             VWN_(is, js) = VWN_(is, js) + dot;
         }
         WSYNC();
@@ -302,11 +321,20 @@ __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int 
     if (lane < n) {
         double di = w->r[lane];
         int pointr = head;
-        for (int jy = 1; jy <= col; ++jy) {
-            di = di + VWY_(lane + 1, pointr) * w->wv[jy - 1] / theta + VWS_(lane + 1, pointr) * w->wv[col + jy - 1];
-            pointr = pointr % m + 1;
+        const double rt = 1.0 / theta;
+        double ay[LB_M], as[LB_M], vy[LB_M], vs[LB_M];       // one batch of LDS reads, then the sum in index order
+#pragma unroll
+        for (int jy = 1; jy <= LB_M; ++jy) {
+            const int jj = jy <= col ? jy : 1;
+            const int pp = (head + jj - 2) % m + 1;
+            ay[jy - 1] = VWY_(lane + 1, pp); as[jy - 1] = VWS_(lane + 1, pp);
+            vy[jy - 1] = w->wv[jj - 1]; vs[jy - 1] = w->wv[col + jj - 1];
         }
-        di = (1.0 / theta) * di;
+        (void)pointr;
+#pragma unroll
+        for (int jy = 1; jy <= LB_M; ++jy)
+            if (jy <= col) di = di + ay[jy - 1] * vy[jy - 1] * rt + as[jy - 1] * vs[jy - 1];
+        di = rt * di;
         w->r[lane] = di;
         w->z[lane] = w->z[lane] + di;
     }
@@ -360,14 +388,23 @@ __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, i
 }
 
 __device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int lane) {
+    if (lane < col) w->wv[lane] = 1.0 / VSY_(lane + 1, lane + 1);      // 1 / SY(k, k) (wv is free between subsm calls)
+    WSYNC();
     int j0 = 0;
     while ((j0 + 1) * (j0 + 2) / 2 <= lane) ++j0;
     const int i = lane - j0 * (j0 + 1) / 2 + 1, j = j0 + 1;      // 1 <= i <= j
     if (j <= col) {
         if (i == 1) VWT_(1, j) = theta * VSS_(1, j);
         else {
+            double pa[LB_M - 1], pb[LB_M - 1], pr[LB_M - 1];
+#pragma unroll
+            for (int k = 1; k <= LB_M - 1; ++k) {
+                const int kk = k <= i - 1 ? k : 1;
+                pa[k - 1] = VSY_(i, kk); pb[k - 1] = VSY_(j, kk); pr[k - 1] = w->wv[kk - 1];
+            }
             double ddum = 0.0;
-            for (int k = 1; k <= i - 1; ++k) ddum = ddum + VSY_(i, k) * VSY_(j, k) / VSY_(k, k);
+#pragma unroll
+            for (int k = 1; k <= LB_M - 1; ++k) if (k <= i - 1) ddum = ddum + pa[k - 1] * pb[k - 1] * pr[k - 1];
             VWT_(i, j) = ddum + theta * VSS_(i, j);
         }
     }
@@ -386,6 +423,17 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
     double theta = 1.0, f, fold = 0.0, gd = 0.0, gdold = 0.0, stp = 0.0, dnorm = 0.0, dtd = 0.0, sbgnrm;
     LbSearch S;
 
+    // -DLBW_PROF (diagnostic build only, tools/prof_lbw.py): per-phase cycle sums replace the solution in w->x
+#ifdef LBW_PROF
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_, tstart_ = __builtin_readcyclecounter();
+#define PT0() t0_ = __builtin_readcyclecounter()
+#define PT1(k) tp[k] += __builtin_readcyclecounter() - t0_
+#define PDUMP() do { WSYNC(); if (lane == 0) { tp[7] = __builtin_readcyclecounter() - tstart_; for (int q_ = 0; q_ < 8; ++q_) w->x[q_] = (double)tp[q_]; } WSYNC(); } while (0)
+#else
+#define PT0()
+#define PT1(k)
+#define PDUMP()
+#endif
     f = lbw_fg(w, K, lane); nfgv = 1;
     sbgnrm = 0.0;
     for (int i = 0; i < n; ++i) sbgnrm = fmax(sbgnrm, fabs(w->g[i]));
@@ -399,8 +447,11 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (lane < n) { w->z[lane] = w->x[lane]; w->r[lane] = -w->g[lane]; }
             WSYNC();
             info = 0;
+            PT0();
             if (updatd) info = lbw_formk(w, iupdat, theta, col, head, lane);
+            PT1(0); PT0();
             if (info == 0) info = lbw_subsm(w, theta, col, head, lane);
+            PT1(1);
             if (info != 0) {
                 col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0;
                 WSYNC();
@@ -416,6 +467,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
         fold = f;
         int ifun = 0, iback = 0, ls_fail = 0, start = 1;
         info = 0;
+        PT0();
         for (;;) {
             gd = lbw_dot8(w->g, w->d);
             if (ifun == 0) {
@@ -433,6 +485,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (iback >= maxls) { ls_fail = 1; break; }
             f = lbw_fg(w, K, lane);
         }
+        PT1(2);
         if (info != 0 || ls_fail) {
             WSYNC();
             if (lane < n) { w->x[lane] = w->t[lane]; w->g[lane] = w->r[lane]; }
@@ -464,10 +517,14 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
         }
         if (dr <= epsmch * ddum) { updatd = 0; continue; }
         updatd = 1; iupdat += 1;
+        PT0();
         lbw_matupd(w, &itail, iupdat, &col, &head, &theta, rr, dr, stp, dtd, lane);
+        PT1(3); PT0();
         if (lbw_formt(w, col, theta, lane) != 0) { col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0; }
+        PT1(4);
     }
     *f_out = f; *nit_out = iter;
+    PDUMP();
     return 0;
 }
 #endif  // __HIPCC__
