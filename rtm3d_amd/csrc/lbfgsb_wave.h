@@ -20,6 +20,16 @@
 
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// -DLBW_PROF=1|2|3 (diagnostic build only, tools/prof_lbw.sh): per-phase cycle sums (s_memtime) in LDS; at the end the first
+// eight replace the solution in w->x, where tools/prof_lbw.py reads them
+#ifdef LBW_PROF
+#define PTB(name) const long long name = __builtin_readcyclecounter()
+#define PTE(name, k) do { if (lane == 0) w->prof[k] += __builtin_readcyclecounter() - name; } while (0)
+#else
+#define PTB(name)
+#define PTE(name, k)
+#endif
+
 struct LbWaveMem {
     double ws[LB_N * LB_M], wy[LB_N * LB_M];
     double sy[LB_M * LB_M], ss[LB_M * LB_M], wt[LB_M * LB_M];
@@ -30,6 +40,9 @@ struct LbWaveMem {
     double x[LB_N], z[LB_N], r[LB_N], d[LB_N], t[LB_N], g[LB_N], wv[LB_M2];
     double terms[64], fterms[16], bc[2];
     double uv[16];
+#ifdef LBW_PROF
+    long long prof[24];
+#endif
 };
 #define VWS_(i, j) w->ws[((j)-1) * LB_N + (i)-1]
 #define VWY_(i, j) w->wy[((j)-1) * LB_N + (i)-1]
@@ -40,6 +53,15 @@ struct LbWaveMem {
 #define VWN1_(i, j) (*((i) == (j) ? &w->wn1d[(i)-1] : &w->wn[((j)-1) * LB_M2 + (i)-1]))      /* i >= j */
 
 struct LbWaveK { double k00, k02, k11, k12; };
+
+// column j of entry `e` of a packed upper triangle (e = j (j + 1) / 2 + i, 0 <= i <= j): closed form + one correction
+// step instead of a search loop (the callers run once per L-BFGS-B iteration in a latency-bound wave)
+__device__ static inline int lbw_tri_col(int e) {
+    int j = (int)((__fsqrt_rn(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    if ((j + 1) * (j + 2) / 2 <= e) ++j;
+    if (j * (j + 1) / 2 > e) --j;
+    return j;
+}
 
 // value of `v` in lane `src` (src wave-uniform) -> every lane, through v_readlane (no LDS round trip)
 __device__ static inline double lbw_bcast(double v, int src) {
@@ -192,31 +214,49 @@ __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double
     return 0;
 }
 
-// forward substitution U' x = b for ONE right-hand side owned by this lane (n <= LB_M), unrolled
-template <int J>
-__device__ static inline void lbw_rhs_step(const double* u, double* bv, int* bad) {
-    const double ajj = u[J * LB_M2 + J];
-    if (ajj == 0.0) { *bad = 1; return; }
-    double dot = 0.0;
-#pragma unroll
-    for (int k = 0; k < J; ++k) dot += u[J * LB_M2 + k] * bv[k];
-    bv[J] = (bv[J] - dot) * ajj;                         // ajj = 1 / u_jj
-}
-#define LBW_RSTEP(J) if (n > J && !bad) lbw_rhs_step<J>(u, bv, &bad);
-__device__ static inline int lbw_rhs_solve(const double* u, double* b, int n) {
-    double bv[LB_M];
-#pragma unroll
-    for (int j = 0; j < LB_M; ++j) bv[j] = b[j < n ? j : 0];
+// forward substitution U' x = b for ONE right-hand side owned by this lane (n <= LB_M), unrolled.  Column-oriented: as
+// soon as x_J exists its term goes into the running sums of all later rows (independent multiply-adds the SIMD pipelines),
+// so the dependent chain is 4 operations per step instead of 2 J + 2; each running sum still receives its terms in the
+// order k = 0, 1, ... from 0.0, i.e. the values are those of the row-oriented lb_trsv_ut.
+// FULL: n == LB_M (every iteration once the memory is full: 16 of ~26) compiles without the per-index guards - the guarded
+// form keeps ~40 uniform predicates alive and spills SGPRs into VGPR lanes around every step.
+template <bool FULL>
+__device__ static inline int lbw_rhs_solve_t(const double* u, double* b, int n) {
+    double bv[LB_M], acc[LB_M];
     int bad = 0;
-    LBW_RSTEP(0) LBW_RSTEP(1) LBW_RSTEP(2) LBW_RSTEP(3) LBW_RSTEP(4)
-    LBW_RSTEP(5) LBW_RSTEP(6) LBW_RSTEP(7) LBW_RSTEP(8) LBW_RSTEP(9)
 #pragma unroll
-    for (int j = 0; j < LB_M; ++j) if (j < n) b[j] = bv[j];
-    return bad;
+    for (int j = 0; j < LB_M; ++j) {
+        bv[j] = b[(FULL || j < n) ? j : 0];
+        acc[j] = 0.0;
+        if ((FULL || j < n) && u[j * LB_M2 + j] == 0.0) bad = 1;
+    }
+    if (bad) return 1;
+#pragma unroll
+    for (int J = 0; J < LB_M; ++J) {
+        if (FULL || J < n) {
+            // this step's row of U only (a compiler that hoists all 45 entries runs out of registers)
+            asm volatile("" ::: "memory");
+            double ur[LB_M];
+#pragma unroll
+            for (int Jp = J; Jp < LB_M; ++Jp) ur[Jp] = u[((FULL || Jp < n) ? Jp : J) * LB_M2 + J];
+            const double xJ = (bv[J] - acc[J]) * ur[J];                    // (reciprocal diagonal)
+            bv[J] = xJ;
+#pragma unroll
+            for (int Jp = J + 1; Jp < LB_M; ++Jp)
+                if (FULL || Jp < n) acc[Jp] += ur[Jp] * xJ;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LB_M; ++j) if (FULL || j < n) b[j] = bv[j];
+    return 0;
+}
+__device__ static inline int lbw_rhs_solve(const double* u, double* b, int n) {
+    return n == LB_M ? lbw_rhs_solve_t<true>(u, b, n) : lbw_rhs_solve_t<false>(u, b, n);
 }
 
 __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, int col, int head, int lane) {
     const int m = LB_M, n = LB_N;
+    PTB(f0_);
     if (iupdat > m) {
         // shift the old part of WN1 one step up-left: three 9x9 index grids (lower triangles of the (1,1)
         // and (2,2) blocks, the full (2,1) block); two-phase (read all, then write all); slots are
@@ -240,6 +280,7 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         for (int q = 0; q < 6; ++q) if (ok[q]) VWN1_(dr[q], dc[q]) = v[q];
         WSYNC();
     }
+    PTE(f0_, 8); PTB(f1_);
     {
         int ipntr = head + col - 1;
         if (ipntr > m) ipntr -= m;
@@ -262,8 +303,11 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         }
         WSYNC();
     }
+    PTE(f1_, 9); PTB(f2_);
+    const float rcol = 1.0f / (float)col;
     for (int e = lane; e < col * col; e += 64) {
-        const int iy = e / col + 1, jy = e % col + 1;
+        const int q = (int)(((float)e + 0.5f) * rcol);       // e / col for e < 100 (exact: margins of 0.5 / col)
+        const int iy = q + 1, jy = e - q * col + 1;
         const int is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
         if (jy <= iy) {
             double v = VWN1_(iy, jy) / theta;
@@ -274,7 +318,9 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         VWN_(jy, is) = (jy < iy) ? -VWN1_(is1, jy) : VWN1_(is1, jy);
     }
     WSYNC();
+    PTE(f2_, 10); PTB(f3_);
     if (lbw_potrf(w->wn, LB_M2, col, lane) != 0) return -1;
+    PTE(f3_, 11); PTB(f4_);
     const int col2 = 2 * col;
     {   // L^-1 (-L_a' + R_z'): one right-hand side (column) per lane
         int bad = 0;
@@ -282,9 +328,9 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         if (__any(bad)) return -1;
         WSYNC();
     }
+    PTE(f4_, 12); PTB(f5_);
     {   // (2,2) block += (L^-1 ...)'(L^-1 ...), upper triangle: one entry per lane (<= 55)
-        int j = 0;
-        while ((j + 1) * (j + 2) / 2 <= lane) ++j;
+        const int j = lbw_tri_col(lane);
         const int i = lane - j * (j + 1) / 2;
         if (j < col) {
             const int is = col + 1 + i, js = col + 1 + j;
@@ -298,7 +344,9 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         }
         WSYNC();
     }
+    PTE(f5_, 13); PTB(f6_);
     if (lbw_potrf(&VWN_(col + 1, col + 1), LB_M2, col, lane) != 0) return -2;
+    PTE(f6_, 14);
     (void)col2;
     return 0;
 }
@@ -314,10 +362,14 @@ __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int 
         else { for (int j = 1; j <= n; ++j) tmp += VWS_(j, pointr) * w->r[j - 1]; w->wv[lane] = theta * tmp; }
     }
     WSYNC();
+    PTB(s0_);
     if (lbw_trsv_ut(w->wn, LB_M2, col2, w->wv, w->bc, lane) != 0) return 1;
+    PTE(s0_, 16);
     if (lane < col) w->wv[lane] = -w->wv[lane];
     WSYNC();
+    PTB(s1_);
     if (lbw_trsv_un(w->wn, LB_M2, col2, w->wv, w->bc, lane) != 0) return 1;
+    PTE(s1_, 17);
     if (lane < n) {
         double di = w->r[lane];
         int pointr = head;
@@ -390,8 +442,7 @@ __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, i
 __device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int lane) {
     if (lane < col) w->wv[lane] = 1.0 / VSY_(lane + 1, lane + 1);      // 1 / SY(k, k) (wv is free between subsm calls)
     WSYNC();
-    int j0 = 0;
-    while ((j0 + 1) * (j0 + 2) / 2 <= lane) ++j0;
+    const int j0 = lbw_tri_col(lane);
     const int i = lane - j0 * (j0 + 1) / 2 + 1, j = j0 + 1;      // 1 <= i <= j
     if (j <= col) {
         if (i == 1) VWT_(1, j) = theta * VSS_(1, j);
@@ -423,16 +474,10 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
     double theta = 1.0, f, fold = 0.0, gd = 0.0, gdold = 0.0, stp = 0.0, dnorm = 0.0, dtd = 0.0, sbgnrm;
     LbSearch S;
 
-    // -DLBW_PROF (diagnostic build only, tools/prof_lbw.py): per-phase cycle sums replace the solution in w->x
 #ifdef LBW_PROF
-    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_, tstart_ = __builtin_readcyclecounter();
-#define PT0() t0_ = __builtin_readcyclecounter()
-#define PT1(k) tp[k] += __builtin_readcyclecounter() - t0_
-#define PDUMP() do { WSYNC(); if (lane == 0) { tp[7] = __builtin_readcyclecounter() - tstart_; for (int q_ = 0; q_ < 8; ++q_) w->x[q_] = (double)tp[q_]; } WSYNC(); } while (0)
-#else
-#define PT0()
-#define PT1(k)
-#define PDUMP()
+    if (lane < 24) w->prof[lane] = 0;
+    WSYNC();
+    const long long tstart_ = __builtin_readcyclecounter();
 #endif
     f = lbw_fg(w, K, lane); nfgv = 1;
     sbgnrm = 0.0;
@@ -447,11 +492,11 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (lane < n) { w->z[lane] = w->x[lane]; w->r[lane] = -w->g[lane]; }
             WSYNC();
             info = 0;
-            PT0();
+            PTB(tk_);
             if (updatd) info = lbw_formk(w, iupdat, theta, col, head, lane);
-            PT1(0); PT0();
+            PTE(tk_, 0); PTB(ts_);
             if (info == 0) info = lbw_subsm(w, theta, col, head, lane);
-            PT1(1);
+            PTE(ts_, 1);
             if (info != 0) {
                 col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0;
                 WSYNC();
@@ -467,7 +512,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
         fold = f;
         int ifun = 0, iback = 0, ls_fail = 0, start = 1;
         info = 0;
-        PT0();
+        PTB(tl_);
         for (;;) {
             gd = lbw_dot8(w->g, w->d);
             if (ifun == 0) {
@@ -485,7 +530,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (iback >= maxls) { ls_fail = 1; break; }
             f = lbw_fg(w, K, lane);
         }
-        PT1(2);
+        PTE(tl_, 2);
         if (info != 0 || ls_fail) {
             WSYNC();
             if (lane < n) { w->x[lane] = w->t[lane]; w->g[lane] = w->r[lane]; }
@@ -517,14 +562,20 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
         }
         if (dr <= epsmch * ddum) { updatd = 0; continue; }
         updatd = 1; iupdat += 1;
-        PT0();
+        PTB(tm_);
         lbw_matupd(w, &itail, iupdat, &col, &head, &theta, rr, dr, stp, dtd, lane);
-        PT1(3); PT0();
+        PTE(tm_, 3); PTB(tt_);
         if (lbw_formt(w, col, theta, lane) != 0) { col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0; }
-        PT1(4);
+        PTE(tt_, 4);
     }
     *f_out = f; *nit_out = iter;
-    PDUMP();
+#ifdef LBW_PROF
+    WSYNC();
+    if (lane == 0) w->prof[7] = __builtin_readcyclecounter() - tstart_;
+    WSYNC();
+    if (lane < 8) w->x[lane] = (double)w->prof[(LBW_PROF - 1) * 8 + lane];      // LBW_PROF = 1, 2, 3: which eight counters
+    WSYNC();
+#endif
     return 0;
 }
 #endif  // __HIPCC__

@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycle counts of the wave-cooperative L-BFGS-B solver on the 64 golden objects.
-Needs a library whose decode3d.hip was compiled with -DLBW_PROF (tools/prof_lbw.sh does that into a scratch copy):
-the solver then writes its phase cycle sums (s_memtime) where the solution normally goes."""
+Needs a library whose decode3d.hip was compiled with -DLBW_PROF=k (tools/prof_lbw.sh builds them into rtm3d_amd/_C/prof<k>):
+the solver then writes eight of its phase cycle sums (s_memtime) where the solution normally goes."""
 import os
 import sys
 
@@ -9,14 +9,17 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtm3d_amd import _lib, model_utils  # noqa: E402
 
-if len(sys.argv) > 1:
-    _lib.LIB_PATH = os.path.abspath(sys.argv[1])      # the diagnostic build, not the in-tree library
-
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])      # the diagnostic build, not the in-tree library
+view = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+NAMES = {1: ['formk', 'subsm', 'line search', 'matupd', 'formt', '-', '-', 'total'],
+         2: ['formk.shift', 'formk.dots', 'formk.fill', 'formk.potrf1', 'formk.rhs', 'formk.upd22', 'formk.potrf2', '-'],
+         3: ['subsm.trsv_ut', 'subsm.trsv_un', '-', '-', '-', '-', '-', '-']}[view]
 g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'decode3d_cases.npz'))
 x, fun, nit, st = model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
 ok = st == 0
-print('objects', len(nit), 'converged', int(ok.sum()), 'iterations mean %.1f max %d' % (nit.mean(), nit.max()))
-names = ['formk', 'subsm', 'line search', 'matupd', 'formt', '-', '-', 'total']
-for k in (0, 1, 2, 3, 4, 7):
-    v = x[ok, k]
-    print('%-12s cycles/object %9.0f   per iteration %7.0f' % (names[k], v.mean(), (v / np.maximum(nit[ok], 1)).mean()))
+if view == 1:
+    print('objects', len(nit), 'converged', int(ok.sum()), 'iterations mean %.1f max %d' % (nit.mean(), nit.max()))
+for k, name in enumerate(NAMES):
+    if name != '-':
+        v = x[ok, k]
+        print('%-14s cycles/object %9.0f   per iteration %7.0f' % (name, v.mean(), (v / np.maximum(nit[ok], 1)).mean()))
