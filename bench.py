@@ -206,7 +206,7 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
         """Device slots vs oracle detections, matched by (class, y, x) cell; only_cells restricts the oracle side."""
         n_dev = det.n.cpu().numpy()
         xs, fs = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy()
-        e = {'ref_detections': 0, 'dev_detections': int(n_dev.sum()), 'matched': 0, 'missed': 0, 'vert_linf_px': 0.0,
+        e = {'ref_detections': 0, 'dev_detections': int(n_dev[:k].sum()), 'matched': 0, 'missed': 0, 'vert_linf_px': 0.0,
              'score_linf': 0.0, 'kept_ref': 0, 'kept_dev': 0, 'kept_both': 0, 'box_linf': None, 'fun_rel_median': None}
         frel = []
         for b in range(k):

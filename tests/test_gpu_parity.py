@@ -22,7 +22,7 @@ from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_
 # largest error MEASURED on the MI355X over every fixture / backbone for that stage (profiles/r02_logit_error.json, written
 # by these tests through tests/util.record_measurement): logits 0.0042, fused map z 0.0063, backbone features 0.0014.
 LOGIT_RTOL = 0.010
-Z_RTOL = 0.013
+Z_RTOL = 0.009
 FEAT_RTOL = 0.003
 HM_RTOL = 0.0055       # heat-map logits alone (measured 0.0028): decides which reference detections are safely above the threshold
 VERT_TOL_PX = 0.25    # vertices of matched detections: 16 regression channels x stride 4

@@ -5,6 +5,7 @@ mkdir -p gpurun_out
 timeout -k 10 700 python -m pytest tests -m gpu -q -x > gpurun_out/full_test.log 2>&1; rc=$?
 tail -4 gpurun_out/full_test.log
 if [ $rc -ne 0 ]; then exit 1; fi
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2 || exit 1
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/$1.json 2> gpurun_out/$1.err || { tail -5 gpurun_out/$1.err; exit 1; }
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --per-op --no-cpu-baseline --no-parity > gpurun_out/$1_perop.json 2> gpurun_out/$1_perop.txt || exit 1
 tail -1 gpurun_out/$1_perop.txt | cut -c1-100
