@@ -54,6 +54,15 @@ struct LbWaveMem {
 
 struct LbWaveK { double k00, k02, k11, k12; };
 
+// The lane index as a value the optimiser cannot see through: index arithmetic derived from it is then redone where it is
+// used (a few VALU instructions) instead of being hoisted out of the iteration loop and kept live across it.  The loop
+// carries ~250 VGPRs of state; hoisted lane-derived indices were spilled to scratch and re-loaded eight times per
+// iteration (a scratch load is a global-memory round trip in a kernel that is nothing but a latency chain).
+__device__ static inline int lbw_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // column j of entry `e` of a packed upper triangle (e = j (j + 1) / 2 + i, 0 <= i <= j): closed form + one correction
 // step instead of a search loop (the callers run once per L-BFGS-B iteration in a latency-bound wave)
 __device__ static inline int lbw_tri_col(int e) {
@@ -159,6 +168,45 @@ __device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
     return 0;
 }
 
+// The same factorisation of TWO independent n x n blocks at once: lanes 0-15 own the columns of `a`, lanes 16-31 those of
+// `b` (same pivot index, same instruction stream - the second matrix is free in a SIMD that runs a serial chain on a
+// handful of lanes).  Used for WN's (1,1) block together with T: formt's factorisation of T is only ever consulted for
+// its positive-definiteness verdict (without bounds nothing calls bmv), and it is the last thing an iteration does before
+// the next formk, so it rides along there.  Returns 0, or 1 if `a` failed, or 2 if `b` failed (the caller resets the
+// limited-memory matrices in both cases, exactly as lb_minimize does after either failure).
+template <int J>
+__device__ static inline int lbw_potrf2_step(double* a, int lda, double* b, int ldb, int n, int lane) {
+    const bool hi = lane >= 16;
+    double* const m = hi ? b : a;
+    const int ld = hi ? ldb : lda;
+    const int i = J + 1 + (lane & 15);
+    const bool act = i < n && lane < 32;
+    const int ic = act ? i : J;
+    double cj[J > 0 ? J : 1], ci[J > 0 ? J : 1];
+#pragma unroll
+    for (int k = 0; k < J; ++k) { cj[k] = m[J * ld + k]; ci[k] = m[ic * ld + k]; }
+    const double ajj0 = m[J * ld + J], aij = m[ic * ld + J];
+    double s = 0.0, dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) { s += cj[k] * cj[k]; dot += cj[k] * ci[k]; }
+    const double ajj = ajj0 - s;
+    const unsigned long long badm = __ballot(!(ajj > 0.0));      // lanes 0-15: `a`; all others hold `b`'s pivot
+    if (badm) return (badm & 0xffffull) ? 1 : 2;
+    const double rinv = lb_rsqrt(ajj);
+    const double v = (aij - dot) * rinv;
+    WSYNC();
+    if (act) m[i * ld + J] = v;
+    if ((lane & 15) == 0 && lane < 32) m[J * ld + J] = rinv;
+    WSYNC();
+    return 0;
+}
+#define LBW_P2STEP(J) if (n <= J) return 0; { const int r_ = lbw_potrf2_step<J>(a, lda, b, ldb, n, lane); if (r_) return r_; }
+__device__ static inline int lbw_potrf2(double* a, int lda, double* b, int ldb, int n, int lane) {
+    LBW_P2STEP(0) LBW_P2STEP(1) LBW_P2STEP(2) LBW_P2STEP(3) LBW_P2STEP(4)
+    LBW_P2STEP(5) LBW_P2STEP(6) LBW_P2STEP(7) LBW_P2STEP(8) LBW_P2STEP(9)
+    return 0;
+}
+
 // U' x = b, single right-hand side in LDS (n <= LB_M2): lane j owns b[j], its partial sum and COLUMN j of U in registers
 // (all operands of the solve are fetched by one batch of LDS reads: a substitution step that waits for its own LDS
 // read costs ~330 cycles, one that only passes the pivot value by v_readlane ~90); lane k also holds the k-th
@@ -255,6 +303,7 @@ __device__ static inline int lbw_rhs_solve(const double* u, double* b, int n) {
 }
 
 __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, int col, int head, int lane) {
+    lane = lbw_opaque(lane);
     const int m = LB_M, n = LB_N;
     PTB(f0_);
     if (iupdat > m) {
@@ -319,7 +368,10 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
     }
     WSYNC();
     PTE(f2_, 10); PTB(f3_);
-    if (lbw_potrf(w->wn, LB_M2, col, lane) != 0) return -1;
+    {   // WN (1,1) block, and T left unfactorised by lbw_formt at the end of the previous iteration
+        const int r2 = lbw_potrf2(w->wn, LB_M2, w->wt, LB_M, col, lane);
+        if (r2 != 0) return r2 == 2 ? -3 : -1;
+    }
     PTE(f3_, 11); PTB(f4_);
     const int col2 = 2 * col;
     {   // L^-1 (-L_a' + R_z'): one right-hand side (column) per lane
@@ -352,6 +404,7 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
 }
 
 __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int head, int lane) {
+    lane = lbw_opaque(lane);
     const int m = LB_M, n = LB_N;
     const int col2 = 2 * col;
     if (lane < col2) {
@@ -374,18 +427,23 @@ __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int 
         double di = w->r[lane];
         int pointr = head;
         const double rt = 1.0 / theta;
-        double ay[LB_M], as[LB_M], vy[LB_M], vs[LB_M];       // one batch of LDS reads, then the sum in index order
+        // two batches of LDS reads (five terms each: 40 registers), each followed by its part of the sum in index order
 #pragma unroll
-        for (int jy = 1; jy <= LB_M; ++jy) {
-            const int jj = jy <= col ? jy : 1;
-            const int pp = (head + jj - 2) % m + 1;
-            ay[jy - 1] = VWY_(lane + 1, pp); as[jy - 1] = VWS_(lane + 1, pp);
-            vy[jy - 1] = w->wv[jj - 1]; vs[jy - 1] = w->wv[col + jj - 1];
+        for (int h = 0; h < 2; ++h) {
+            double ay[LB_M / 2], as[LB_M / 2], vy[LB_M / 2], vs[LB_M / 2];
+#pragma unroll
+            for (int q = 0; q < LB_M / 2; ++q) {
+                const int jy = h * (LB_M / 2) + q + 1;
+                const int jj = jy <= col ? jy : 1;
+                const int pp = (head + jj - 2) % m + 1;
+                ay[q] = VWY_(lane + 1, pp); as[q] = VWS_(lane + 1, pp);
+                vy[q] = w->wv[jj - 1]; vs[q] = w->wv[col + jj - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < LB_M / 2; ++q)
+                if (h * (LB_M / 2) + q + 1 <= col) di = di + ay[q] * vy[q] * rt + as[q] * vs[q];
         }
         (void)pointr;
-#pragma unroll
-        for (int jy = 1; jy <= LB_M; ++jy)
-            if (jy <= col) di = di + ay[jy - 1] * vy[jy - 1] * rt + as[jy - 1] * vs[jy - 1];
         di = rt * di;
         w->r[lane] = di;
         w->z[lane] = w->z[lane] + di;
@@ -396,6 +454,7 @@ __device__ static inline int lbw_subsm(LbWaveMem* w, double theta, int col, int 
 
 __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, int* col, int* head, double* theta,
                                          double rr, double dr, double stp, double dtd, int lane) {
+    lane = lbw_opaque(lane);
     const int m = LB_M, n = LB_N;
     {   // (value selection, not stores through col / head per branch: see lb_dcstep)
         const bool grow = iupdat <= m;
@@ -440,6 +499,7 @@ __device__ static inline void lbw_matupd(LbWaveMem* w, int* itail, int iupdat, i
 }
 
 __device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int lane) {
+    lane = lbw_opaque(lane);
     if (lane < col) w->wv[lane] = 1.0 / VSY_(lane + 1, lane + 1);      // 1 / SY(k, k) (wv is free between subsm calls)
     WSYNC();
     const int j0 = lbw_tri_col(lane);
@@ -447,20 +507,24 @@ __device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int 
     if (j <= col) {
         if (i == 1) VWT_(1, j) = theta * VSS_(1, j);
         else {
-            double pa[LB_M - 1], pb[LB_M - 1], pr[LB_M - 1];
-#pragma unroll
-            for (int k = 1; k <= LB_M - 1; ++k) {
-                const int kk = k <= i - 1 ? k : 1;
-                pa[k - 1] = VSY_(i, kk); pb[k - 1] = VSY_(j, kk); pr[k - 1] = w->wv[kk - 1];
-            }
             double ddum = 0.0;
 #pragma unroll
-            for (int k = 1; k <= LB_M - 1; ++k) if (k <= i - 1) ddum = ddum + pa[k - 1] * pb[k - 1] * pr[k - 1];
+            for (int h = 0; h < 1; ++h) {                  // one batch of reads, then the sum in index order
+                double pa[9], pb[9], pr[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int k = h * 9 + q + 1;
+                    const int kk = k <= i - 1 ? k : 1;
+                    pa[q] = VSY_(i, kk); pb[q] = VSY_(j, kk); pr[q] = w->wv[kk - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) if (h * 9 + q + 1 <= i - 1) ddum = ddum + pa[q] * pb[q] * pr[q];
+            }
             VWT_(i, j) = ddum + theta * VSS_(i, j);
         }
     }
     WSYNC();
-    return lbw_potrf(w->wt, LB_M, col, lane) != 0 ? -3 : 0;
+    return 0;            // T's factorisation (a pass / fail verdict only) runs inside the next lbw_formk: lbw_potrf2
 }
 
 // Driver: identical control flow to lb_minimize (lbfgsb.h).  w->x holds x0 on entry, the result on exit.
