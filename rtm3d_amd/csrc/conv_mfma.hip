@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void conv_mfma_deep_kernel(const ConvKArgs a, 
         // The partial tiles cross XCDs (one L2 each).  A device-scope fence would do (release = write back the L2, acquire =
         // invalidate it) but every workgroup pays for the whole-cache operations: measured 45-80 us per layer.  Instead the
         // slab is only ever touched with agent-scope relaxed atomic 8-byte accesses (sc1: write-through / L2-coherent
-        // reads), ordered against the ticket by the waves' own vmcnt(0) + the workgroup barrier.
+        // reads), ordered against the ticket by the waves' own vmcnt(0) + the workgroup barrier: the hand-off form of
+        // MI355X_MICROARCH.md 'Hand-offs measured with sc1 loads', first row (one lane per storing workgroup adds to one
+        // counter after every wave's vmcnt(0) and a barrier; the workgroup whose add came last reads; one workgroup per CU).
         unsigned long long* mine = (unsigned long long*)(a.slab + (size_t)blockIdx.z * split_stride
                                                          + ((size_t)blockIdx.y * a.MT * a.NT + tile) * tile_floats) + tid;
 #pragma unroll
