@@ -12,7 +12,7 @@ overwrites slot i % depth.  No host synchronisation inside; `results(i)` hands o
 finished step after waiting on B_i.
 
 Small batches (<= SMALL_BATCH images): the solve of a handful of objects is ONE wavefront per object walking a serial
-fp64 iteration (measured 1.46 ms for 15 objects at bs=1, profiles/r02_small_batch.txt) - longer than the whole network
+fp64 iteration (1.46 ms for 15 objects at bs=1 when this was measured, ~1.0 ms now; profiles/r02_small_batch.txt) - as long as the whole network
 (1.27 ms).  A single side stream would serialise the decodes of consecutive steps and bound the step at that latency, so
 small batches use depth 3 and one side stream per slot: decode3d(i) and decode3d(i+1) overlap each other and the step
 is bound by the network again.
@@ -27,7 +27,7 @@ from .model_utils import Boxes3D, decode3d_slots
 from . import distributed as rdist
 
 
-SMALL_BATCH = 2      # batches whose 3D decode (a serial fp64 iteration per object, ~1.5 ms) outlasts the network
+SMALL_BATCH = 2      # batches whose 3D decode (a serial fp64 iteration per object, ~1 ms) is about as long as the network
 
 
 class Detect3DPipeline(object):
