@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
     ap.add_argument('--depth', type=int, default=0, help='pipeline slots (0: automatic)')
     ap.add_argument('--side-streams', type=int, default=0, help='decode3d side streams (0: automatic)')
+    ap.add_argument('--no-conv128', action='store_true', help='DIAGNOSTIC (A/B): 128->128 3x3 layers on the generic kernel instead of conv128_halo')
     ap.add_argument('--serial', action='store_true', help='single stream, no decode3d/forward overlap')
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
@@ -294,6 +295,9 @@ def main():
     if args.v2_min_tiles is not None:
         from rtm3d_amd import plan as _plan
         _plan.V2_MIN_TILES = args.v2_min_tiles
+    if args.no_conv128:
+        from rtm3d_amd import plan as _plan
+        _plan.USE_CONV128 = False
     bb = args.backbone
     B, H, W = args.batch, args.height, args.width
     cfg = rtm3d_amd.kitti_config(bb)
@@ -415,6 +419,8 @@ def main():
             out['INVALID'] = 'diagnostic run without the 3D decode'
         if args.v2_min_tiles is not None:
             out['DIAGNOSTIC_v2_min_tiles'] = args.v2_min_tiles
+        if args.no_conv128:
+            out['DIAGNOSTIC_no_conv128'] = True
         if args.heat_bias is not None:
             out['DIAGNOSTIC'] = 'heat-map bias overridden to %g (not the benchmark workload)' % args.heat_bias
         if args.per_op:

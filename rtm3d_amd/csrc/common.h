@@ -141,6 +141,8 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
 bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 bool conv64_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
+bool conv128_halo_supported(const ConvKArgs& a, int groups);
+hipError_t launch_conv128_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);
 bool conv_smallc_supported(int cin, int cout, int ntaps);
 hipError_t launch_nchw_to_nhwc4(const float* in, f16* out, int B, int H, int W, int Hp, int Wp, int P, hipStream_t s);

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
 
 struct Op {
     OpKind kind;
@@ -269,6 +269,18 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[0].w_off = 0; a.g[0].bias_off = 0;
         op.kind = OP_CONV64_HALO; op.bn_tile = 64; op.ticket_slot = ctx->ticket_slots_used++;
         op.name = "conv3x3_c64_halo";
+    } else if (d->kernel == 6) {
+        // 128 -> 128 channel 3x3 halo kernel, weights streamed through an LDS ring (conv128_halo.hip); the weight blob is
+        // the generic kernel's packing for 128-channel tiles
+        if (d->out_nchw_f32) RT_FAIL("op_conv(conv128): NCHW output unsupported");
+        a.cpt = 2; a.ksteps = 18; a.MT = 0; a.NT = 1;
+        if (!conv128_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv128): needs one 128->128 3x3 stride-1 conv on a map with W %% 32 == 0, H %% 8 == 0");
+        if (d->bn_tile != 128 || wbytes != (size_t)9 * 128 * 128 * sizeof(f16) || bbytes != 128 * sizeof(float)) RT_FAIL("op_conv(conv128): weight/bias blob size mismatch (expects the bn_tile = 128 packing)");
+        if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv(conv128): out of ticket counters");
+        if (ensure_tile_ctr(ctx)) return 1;
+        a.g[0].w_off = 0; a.g[0].bias_off = 0;
+        op.kind = OP_CONV128_HALO; op.bn_tile = 128; op.ticket_slot = ctx->ticket_slots_used++;
+        op.name = "conv3x3_c128_halo";
     } else if (d->kernel == 0) {
         const int BN = d->bn_tile;
         if (BN != 16 && BN != 32 && BN != 64 && BN != 128) RT_FAIL("op_conv: bn_tile must be 16/32/64/128");
@@ -558,6 +570,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
+        case OP_CONV128_HALO: e = launch_conv128_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_STEM_FUSED: {
             StemFusedArgs a = op.sf;
             a.x_nchw = d_in;                     // null: the NHWC4 tensor was filled by rtm3d_preprocess_batch

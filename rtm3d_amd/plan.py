@@ -466,6 +466,19 @@ def conv64_eligible(op):
             and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0)
 
 
+USE_CONV128 = True
+C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small-launch kernels of conv_mfma.hip do better
+
+
+def conv128_eligible(op, B):
+    """3x3 / stride 1 / dilation 1 / 128 -> 128 channels on a map that 8 x 32 pixel tiles cover, with at least one tile per
+    CU: conv128_halo.hip (DLA-34 level3, ResNet layer2)."""
+    taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    return (op['cin'] == 128 and op['cout'] == 128 and op['groups'] == 1 and op['in_stride'] == 1 and op['out_scale'] == 1
+            and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0
+            and B * (op['Hm'] // 8) * (op['Wm'] // 32) >= C128_MIN_TILES)
+
+
 def pack_conv64_weights(wt):
     """wt: (9, 64, 64) fp32 [tap][cout][cin] -> fp16 [tap][k half][16-channel tile][lane = fk*16 + row][8]: the MFMA A
     fragments a wave of conv64_halo.hip keeps in registers."""
@@ -697,8 +710,13 @@ class RealizedPlan(object):
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
         if variant is None:
-            variant = 5 if conv64_eligible(op) else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
-        if variant == 5:
+            variant = (5 if conv64_eligible(op) else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)
+                       else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw']))
+        if variant == 6:
+            d.kernel, d.bn_tile = 6, 128
+            d.w_blob = self._blob(self._packed(op, 0, 'mfma', 128, lambda: pack_mfma_weights(op['w'][0], 128)[0]))
+            d.bias_blob = self._blob(np.ascontiguousarray(op['bias'][0], np.float32))
+        elif variant == 5:
             assert conv64_eligible(op), op['name']
             d.kernel, d.bn_tile = 5, 64
             d.w_blob = self._blob(self._packed(op, 0, 'c64', 0, lambda: pack_conv64_weights(op['w'][0])))
