@@ -270,12 +270,13 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         op.kind = OP_CONV64_HALO; op.bn_tile = 64; op.ticket_slot = ctx->ticket_slots_used++;
         op.name = "conv3x3_c64_halo";
     } else if (d->kernel == 6) {
-        // 128 -> 128 channel 3x3 halo kernel, weights streamed through an LDS ring (conv128_halo.hip); the weight blob is
-        // the generic kernel's packing for 128-channel tiles
+        // 3x3 halo kernel for multiples of 128 channels, weights streamed through an LDS ring (conv128_halo.hip); the weight
+        // blob is the generic kernel's packing for 128-channel tiles
         if (d->out_nchw_f32) RT_FAIL("op_conv(conv128): NCHW output unsupported");
-        a.cpt = 2; a.ksteps = 18; a.MT = 0; a.NT = 1;
-        if (!conv128_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv128): needs one 128->128 3x3 stride-1 conv on a map with W %% 32 == 0, H %% 8 == 0");
-        if (d->bn_tile != 128 || wbytes != (size_t)9 * 128 * 128 * sizeof(f16) || bbytes != 128 * sizeof(float)) RT_FAIL("op_conv(conv128): weight/bias blob size mismatch (expects the bn_tile = 128 packing)");
+        a.cpt = d->cin / 64; a.ksteps = 9 * a.cpt; a.MT = 0; a.NT = 1;
+        if (!conv128_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv128): needs one 3x3 stride-1 conv with cin, cout %% 128 == 0 on a map with W %% 32 == 0, H %% 8 == 0");
+        if (d->bn_tile != 128 || wbytes != (size_t)9 * d->cin * d->cout * sizeof(f16) || bbytes != (size_t)d->cout * sizeof(float))
+            RT_FAIL("op_conv(conv128): weight/bias blob size mismatch (expects the bn_tile = 128 packing)");
         if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv(conv128): out of ticket counters");
         if (ensure_tile_ctr(ctx)) return 1;
         a.g[0].w_off = 0; a.g[0].bias_off = 0;

@@ -472,7 +472,8 @@ C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small
 
 def conv128_eligible(op, B):
     """3x3 / stride 1 / dilation 1 / 128 -> 128 channels on a map that 8 x 32 pixel tiles cover, with at least one tile per
-    CU: conv128_halo.hip (DLA-34 level3, ResNet layer2)."""
+    CU: conv128_halo.hip (DLA-34 level3, ResNet layer2).  (The kernel takes any multiples of 128 channels; the plan only
+    sends it the layers it was measured to win on.)"""
     taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
     return (op['cin'] == 128 and op['cout'] == 128 and op['groups'] == 1 and op['in_stride'] == 1 and op['out_scale'] == 1
             and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0

@@ -57,6 +57,7 @@ CONV_CASES = [
     (3, 24, 96, 128, 128, 3, 1, 1, False, False, 6, 64),    # conv128 halo: no ReLU, input slice of a wider tensor, 27 tiles
     (1, 8, 32, 128, 128, 3, 1, 1, True, False, 6, 0),       # conv128 halo: a single tile
     (8, 96, 160, 128, 128, 3, 1, 1, True, True, 6, 0),      # conv128 halo: 480 tiles on 256 workgroups (ticket hand-out)
+    (2, 16, 64, 256, 256, 3, 1, 1, True, True, 6, 0),       # conv128 halo: two channel tiles per pixel tile, 4 input chunks, residual
     (2, 16, 24, 16, 16, 3, 1, 1, True, False, 3, 0),        # smallc 16->16
     (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
     (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
