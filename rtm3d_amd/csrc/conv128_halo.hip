@@ -17,6 +17,10 @@
 //     Every wave issues exactly 3 DMA instructions per K-step (2 weight + 1 halo; halo slots past the end re-stage the
 //     last piece), so the wait in front of a K-step is the immediate s_waitcnt vmcnt(3);
 //   * one raw s_barrier per K-step; a wave owns 64 pixels x 64 channels (16 accumulator tiles);
+//   * measured on this kernel and not kept (PMC: MFMA pipe 35-47 % busy, 0 LDS bank conflicts, waves 45 % of their cycles in
+//     s_waitcnt): either DMA stream switched off (timing only) -2 % / 0 %; a 4-slot weight ring with three K-steps for a
+//     tile to land 0 %; operand fragments of K-step s + 1 fetched during the MFMAs of K-step s (+80 VGPRs) -3 %; the two
+//     wave groups half a K-step apart with two barriers per K-step (the conv256 stagger) +10 %;
 //   * items are handed out by one atomic ticket counter per op (zeroed at the head of every forward by the runtime);
 //     consecutive items are the channel tiles of one pixel tile (shared halo in L2);
 //   * epilogue: bias (+ residual) + ReLU, v_permlane16_swap pairs two 16-channel MFMA tiles -> 16-byte stores.  (Keeping the
