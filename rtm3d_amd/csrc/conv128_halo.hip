@@ -20,7 +20,8 @@
 //   * measured on this kernel and not kept (PMC: MFMA pipe 35-47 % busy, 0 LDS bank conflicts, waves 45 % of their cycles in
 //     s_waitcnt): either DMA stream switched off (timing only) -2 % / 0 %; a 4-slot weight ring with three K-steps for a
 //     tile to land 0 %; operand fragments of K-step s + 1 fetched during the MFMAs of K-step s (+80 VGPRs) -3 %; the two
-//     wave groups half a K-step apart with two barriers per K-step (the conv256 stagger) +10 %;
+//     wave groups half a K-step apart with two barriers per K-step (the conv256 stagger) +10 %; no LDS operand reads at all
+//     (timing only) -12 %, no barriers -2 %: what is left is per-item cost (an item is 9.7 us of MFMA time, a conv256 tile 40);
 //   * items are handed out by one atomic ticket counter per op (zeroed at the head of every forward by the runtime);
 //     consecutive items are the channel tiles of one pixel tile (shared halo in L2);
 //   * epilogue: bias (+ residual) + ReLU, v_permlane16_swap pairs two 16-channel MFMA tiles -> 16-byte stores.  (Keeping the
