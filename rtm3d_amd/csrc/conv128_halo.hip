@@ -22,9 +22,12 @@
 //     tile to land 0 %; operand fragments of K-step s + 1 fetched during the MFMAs of K-step s (+80 VGPRs) -3 %; the two
 //     wave groups half a K-step apart with two barriers per K-step (the conv256 stagger) +10 %; no LDS operand reads at all
 //     (timing only) -12 %, no barriers -2 %: what is left is per-item cost (an item is 9.7 us of MFMA time, a conv256 tile 40);
-//   * items are handed out by one atomic ticket counter per op (zeroed at the head of every forward by the runtime): one
-//     synchronous draw up front, then one per item, issued in the item's first K-step and picked up at the start of its last
-//     phase, so nobody waits for its round trip;
+//   * items are handed out by one atomic ticket counter per op (zeroed at the head of every forward by the runtime): ONE draw
+//     of three up front, then one per item by thread 0 at the item's end.  (Measured and not kept: issuing the per-item
+//     draw early and picking it up later through a sentinel - no gain once the up-front draws were one, and unsafe in
+//     principle: the compiler may copy a register that the hardware is still going to write; letting it land in an AGPR
+//     instead makes the allocator split the file 128/128 and spill.  A static first item per workgroup: same speed alone,
+//     slower with the 3D decode beside it.);
 //     consecutive items are the channel tiles of one pixel tile (shared halo in L2);
 //   * epilogue: bias (+ residual) + ReLU, v_permlane16_swap pairs two 16-channel MFMA tiles -> 16-byte stores.  (Keeping the
 //     previous tile's stores and this tile's residual loads in flight across the first K-steps, with the wait counts
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
     constexpr int WPN = 8 / WCN;                            // 4 pixel groups of 64 (2 rows x 32)
     constexpr int ROWS = 8 / WPN;                           // tile rows per wave
     __shared__ __attribute__((aligned(128))) f16 lds[(2 * XBUF_PIECES + C128_NSW * WSLOT_PIECES) * 8];
-    __shared__ int tk[2];
+    __shared__ int tk[3];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,16 +82,14 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
     const uint32_t lds_w = lds_x + (uint32_t)(2 * XBUF_PIECES * 16);
     const f16* const wsrc = a.wgt + g.w_off + tid * 8;       // this thread's first piece of a K-step tile
 
-    // Items are handed out by the op's ticket counter (zeroed at the head of every forward by the runtime), so a workgroup
-    // whose CU is still held by another stream's waves simply takes fewer - and one that starts late finds nothing left
-    // instead of a statically assigned item that everybody then waits for.  ONE synchronous draw up front (three cost
-    // 8-10 us per launch: 768 returning atomics on one word, ~88 draws per microsecond, three round trips in a row).
-    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 1u);
+    // (ONE draw of three: three separate returning atomics per workgroup - 768 on one word, three round trips in a row
+    // before the first MFMA - cost 8-10 us per launch; the word serves ~88 draws per microsecond)
+    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
     __syncthreads();
-    int cur = __builtin_amdgcn_readfirstlane(tk[0]);
+    const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
+    int cur = tk0, nxt = tk0 + 1, nn = tk0 + 2;
     if (cur >= total) return;
-    __syncthreads();                                // tk[0] is reused below
-    int nxt = 0;
+    __syncthreads();                                // tk[0..1] are reused as the per-item slots below
 
     // item v = pixel tile v / NT, channel tile v % NT
     auto halo_origin = [&](int v) -> const f16* {
@@ -132,25 +133,22 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int it = 0;
-    unsigned int ticket = 0;
     f32x4 acc[4][4];
     for (;;) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bool more = false;
-        const int nt_cur = cur % NT;
-        int nt_nxt = nt_cur;
+        const bool more = nxt < total;
+        const int nt_cur = cur % NT, nt_nxt = more ? nxt % NT : nt_cur;
         const f16* const src_cur = halo_origin(cur);
-        const f16* src_nxt = src_cur;
+        const f16* const src_nxt = more ? halo_origin(nxt) : src_cur;          // (no next item: a harmless re-stage)
 #pragma unroll 1
         for (int chunk = 0; chunk < cpt; ++chunk) {
             // halo buffer of this phase = chunk & 1 (an even number of phases per item); the next phase's halo goes to the other
             const bool last = chunk + 1 == cpt;
-            const f16* src_next = src_cur + 64 * (chunk + 1);      // (the last phase replaces these in its first K-step)
-            int nt_next = nt_cur;
-            const int chunk_next = last ? 0 : chunk + 1;
+            const f16* const src_next = last ? src_nxt : src_cur + 64 * (chunk + 1);
+            const int nt_next = last ? nt_nxt : nt_cur, chunk_next = last ? 0 : chunk + 1;
             const int xb = chunk & 1;
             uint32_t hb = lds_x + (uint32_t)(xb * XBUF_PIECES * 16);
             asm volatile("" : "+v"(hb));            // keep the 9 x 2 operand addresses of a phase out of the loop-carried state
@@ -162,27 +160,7 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();           // ... for every wave; ring slot (t + 2) % 3 and the other halo buffer are free
                 __builtin_amdgcn_sched_barrier(0);
-                // The next item's ticket.  A returning atomic costs a 2-3 us round trip, so thread 0 issues it in the item's
-                // first K-step and picks the value up at the end of the last-but-one phase; the item's last phase, which
-                // prefetches the next item's halo and first weight tiles, reads it from LDS behind its first barrier.  The
-                // counted waits cannot vouch for the atomic (measured: a returning atomic may complete ahead of older
-                // LDS-DMA loads, so it must not be counted into vmcnt(N) either), hence a sentinel: the destination
-                // register holds ~0 until the value lands; should it still be there, wait for everything.
-                if (chunk == 0 && t == 0 && tid == 0) {
-                    ticket = 0xffffffffu;
-                    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(ticket) : "v"(ticket_ctr), "v"(1u) : "memory");
-                }
-                if (chunk + 2 == cpt && t == 8 && tid == 0) {
-                    asm volatile("" : "+v"(ticket));
-                    if (ticket == 0xffffffffu) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) : : "memory");
-                    tk[it & 1] = (int)ticket;           // (slot it & 1 was last read an item ago)
-                }
-                if (last && t == 0) {
-                    nxt = __builtin_amdgcn_readfirstlane(tk[it & 1]);
-                    more = nxt < total;
-                    if (more) { src_nxt = halo_origin(nxt); nt_nxt = nxt % NT; }     // (else: a harmless re-stage of this item)
-                    src_next = src_nxt; nt_next = nt_nxt;
-                }
+                if (chunk == 0 && t == 0 && it > 0) nn = __builtin_amdgcn_readfirstlane(tk[(it - 1) & 1]);   // drawn during the previous item
                 {
                     if (t + 2 < 9) issue_w(nt_cur, t + 2, chunk, (t + 2) % C128_NSW);
                     else issue_w(nt_next, t + 2 - 9, chunk_next, (t + 2) % C128_NSW);
@@ -216,6 +194,8 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
                             acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][c], xf[kk][p], acc[c][p], 0, 0, 0);
             }
         }
+        // one more ticket (for the item after `nn`); slot it & 1 was read by everyone at least one barrier ago
+        if (tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
 
         // ---- epilogue of `cur`
         {
@@ -263,7 +243,7 @@ __global__ __launch_bounds__(512) void conv128_halo_kernel(const ConvKArgs a, un
             }
         }
         if (!more) break;
-        cur = nxt;
+        cur = nxt; nxt = nn;
         ++it;
     }
 }

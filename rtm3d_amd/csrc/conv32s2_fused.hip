@@ -57,15 +57,12 @@ __global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args 
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
 
-    if (tid == 0) {
-        tk[0] = (int)atomicAdd(ticket_ctr, 1u);
-        tk[1] = (int)atomicAdd(ticket_ctr, 1u);
-        tk[2] = (int)atomicAdd(ticket_ctr, 1u);
-    }
+    // (ONE draw of three: three separate returning atomics per workgroup - 768 on one word, three round trips in a row
+    // before the first MFMA - cost 8-10 us per launch; the word serves ~88 draws per microsecond)
+    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
     __syncthreads();
-    int cur = __builtin_amdgcn_readfirstlane(tk[0]);
-    int nxt = __builtin_amdgcn_readfirstlane(tk[1]);
-    int nn = __builtin_amdgcn_readfirstlane(tk[2]);
+    const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
+    int cur = tk0, nxt = tk0 + 1, nn = tk0 + 2;
     if (cur >= total) return;
     __syncthreads();
 

@@ -72,15 +72,12 @@ __global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, uns
     // Tickets: three drawn up front (current tile, next, the one after), one more per tile by thread 0, published through
     // LDS behind the next tile's barrier.  Draws past the end are harmless: the runtime zeroes the counter at the head of
     // every forward.
-    if (tid == 0) {
-        tk[0] = (int)atomicAdd(ticket_ctr, 1u);
-        tk[1] = (int)atomicAdd(ticket_ctr, 1u);
-        tk[2] = (int)atomicAdd(ticket_ctr, 1u);
-    }
+    // (ONE draw of three: three separate returning atomics per workgroup - 768 on one word, three round trips in a row
+    // before the first MFMA - cost 8-10 us per launch; the word serves ~88 draws per microsecond)
+    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
     __syncthreads();
-    int cur = __builtin_amdgcn_readfirstlane(tk[0]);
-    int nxt = __builtin_amdgcn_readfirstlane(tk[1]);
-    int nn = __builtin_amdgcn_readfirstlane(tk[2]);
+    const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
+    int cur = tk0, nxt = tk0 + 1, nn = tk0 + 2;
     if (cur >= total) return;
     __syncthreads();                                // tk[0..1] are reused as the per-tile slots below
 
