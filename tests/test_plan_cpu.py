@@ -78,3 +78,18 @@ def test_weight_cache_is_transparent_and_persistent(tmp_path):
     sd2 = dict(sd); sd2['backbone.conv1.weight'] = sd['backbone.conv1.weight'] + 1
     assert state_dict_digest(sd2) != state_dict_digest(sd)
     assert WeightCache(sd2, directory=str(tmp_path)).entries == {}
+
+
+def test_halo_kernel_selection():
+    """Which layers the plan sends to the persistent halo kernels: DLA-34's three 64 -> 64 level2 convs (conv64_halo.hip) at any
+    batch, its seven 128 -> 128 level3 convs (conv128_halo.hip) only when there is at least one 8 x 32 tile per CU."""
+    sd = weights.synth_state_dict('DLA-34', 1, 'trained')
+    for B, want128 in ((32, 7), (8, 7), (1, 0)):
+        P = plan_mod.build_plan(sd, 'DLA-34', B, 384, 1280)
+        convs = [op for op in P.ops if op['op'] == 'conv']
+        assert sum(1 for op in convs if plan_mod.conv64_eligible(op)) == 3
+        c128 = [op for op in convs if plan_mod.conv128_eligible(op, B)]
+        assert len(c128) == want128
+        assert all(op['name'].startswith('backbone.level3.') and (op['Hm'], op['Wm']) == (48, 160) for op in c128)
+    P = plan_mod.build_plan(sd, 'DLA-34', 32, 128, 256)         # 16 x 32 level3 map: 8 x 32 tiles fit, but only 64 of them
+    assert not any(plan_mod.conv128_eligible(op, 32) for op in P.ops if op['op'] == 'conv')
