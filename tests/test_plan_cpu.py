@@ -84,7 +84,7 @@ def test_halo_kernel_selection():
     """Which layers the plan sends to the persistent halo kernels: DLA-34's three 64 -> 64 level2 convs (conv64_halo.hip) at any
     batch, its seven 128 -> 128 level3 convs (conv128_halo.hip) only when there is at least one 8 x 32 tile per CU."""
     sd = weights.synth_state_dict('DLA-34', 1, 'trained')
-    for B, want128 in ((32, 7), (8, 7), (1, 0)):
+    for B, want128 in ((32, 7), (16, 7), (8, 0), (1, 0)):      # 30 tiles per image: 480 / 240 / 30 at B = 16 / 8 / 1
         P = plan_mod.build_plan(sd, 'DLA-34', B, 384, 1280)
         convs = [op for op in P.ops if op['op'] == 'conv']
         assert sum(1 for op in convs if plan_mod.conv64_eligible(op)) == 3
