@@ -269,14 +269,33 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     e_pl = match_e2e(det2, boxes2, dets_p, raws_p, only)
     out['e2e'] = e_nat
     out['e2e_planted'] = e_pl
+    # (c) the same two comparisons with the network in the fp32 VERIFICATION mode (Model.forward_logits_fp32: the same plan
+    # on fp32 tensors, rtm3d_amd/verify.py) and the product's own decode kernels: what is left is fp32 round-off plus the
+    # reference solver's own sensitivity to it (profiles/r02_solver_sensitivity.txt)
+    lg32 = model.forward_logits_fp32(x_dev[:k])
+    det3 = model.decode2d(lg32)
+    boxes3 = decode3d_slots(det3, Kd, dim_ref, [0, -0.5, 20])
+    lg32p = [l + torch.from_numpy(p_ - n_.numpy()).to(dev) for l, p_, n_ in zip(lg32, lg, logits_ref)]
+    det4 = model.decode2d(lg32p)
+    boxes4 = decode3d_slots(det4, Kd, dim_ref, [0, -0.5, 20])
+    torch.cuda.synchronize(dev)
+    model.release_verify()                     # free the fp32 workspace
+    out['e2e_fp32_mode'] = match_e2e(det3, boxes3, dets_ref, raws_nat)
+    out['e2e_fp32_mode_planted'] = match_e2e(det4, boxes4, dets_p, raws_p, only)
+    out['e2e_fp32_mode']['logit_linf_rel'] = max(float((a[:k].cpu() - b_).abs().max() / max(1.0, float(b_.abs().max())))
+                                                 for a, b_ in zip(lg32, logits_ref))
     # the names VERDICT r01 asked for, flat
     out.update({'stage_box_linf': st['box_linf'], 'e2e_vert_linf_px': max(e_nat['vert_linf_px'], e_pl['vert_linf_px']),
-                'e2e_box_linf': e_pl['box_linf'], 'matched': e_nat['matched'] + e_pl['matched'], 'missed': e_nat['missed'] + e_pl['missed']})
+                'e2e_box_linf': e_pl['box_linf'], 'matched': e_nat['matched'] + e_pl['matched'], 'missed': e_nat['missed'] + e_pl['missed'],
+                'e2e_box_linf_fp32_mode': out['e2e_fp32_mode_planted']['box_linf'],
+                'e2e_box_median_fp32_mode': out['e2e_fp32_mode_planted'].get('box_median')})
     out['note'] = ('stage: device decode kernels on the oracle fp32 logits of the benchmark images with %d exact cuboid projections '
                    'planted per image (bar: identical indices, boxes 1e-4).  e2e: fp16 network on the device vs the fp32 oracle end to '
                    'end, detections matched by (class, y, x); the synthetic-weight workload itself has no cuboid-consistent key points '
                    '(the reference keeps none), so box L-inf is measured on the same planted cuboids carried through the network '
-                   'additively (device logits + oracle(planted - natural)): planted vertices on the device = exact + real fp16 error' % planted)
+                   'additively (device logits + oracle(planted - natural)): planted vertices on the device = exact + real fp16 error.  '
+                   'e2e_fp32_mode*: the same comparisons with the network in the fp32 verification mode (same plan, fp32 tensors, '
+                   'fp64 accumulation; product decode kernels)' % planted)
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 3
+#define RTM3D_ABI_VERSION 4
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -253,6 +253,47 @@ int rtm3d_stream_destroy(void* stream);
 int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                           const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                           double* d_fun, int32_t* d_nit, int32_t* d_status);
+
+/* ------------------------------------------------------------------ fp32 verification executor (regime ii)
+ * The product path stores activations and weights in fp16; BASELINE's "3D-box L-inf vs CPU ref" through fp16 logits is
+ * bounded by that storage.  These three stateless entry points run the SAME recorded plan
+ * (rtm3d_amd/plan.py: tap tables, channel slices, sub-pixel phases, folded BN, composed 1x1 pairs) on padded NHWC *fp32*
+ * tensors with fp32 weights and fp64 accumulation, so that Model.forward_logits_fp32 -> rtm3d_decode2d ->
+ * rtm3d_decode3d_slots can be compared with the reference's fp32 CPU path (models/model.py:20-27, :29-75,
+ * utils/model_utils.py:264-312) to fp32 round-off.  Verification only: simple kernels (no MFMA, no LDS), ~100x slower than
+ * rtm3d_forward, never selected by Model.forward.
+ * rtm3d_vtensor: channel slice [coff, coff + c) of a padded NHWC fp32 buffer [B][Hp][Wp][C] with border P (zeros), all
+ * device memory owned by the caller.                                                                                    */
+typedef struct rtm3d_vtensor {
+    float* d;
+    int Hp, Wp, C, P, coff;
+} rtm3d_vtensor;
+
+/* One group of rtm3d_conv_desc (same iteration domain, tap and output-pixel semantics) in fp32.
+ * d_w: fp32 [ntaps][cin][cout]; d_bias: fp32 [cout] (BN folded).  cin, in.C and in.coff must be multiples of 4.
+ * out_nchw_f32 != 0: out.d is an fp32 NCHW (B, cout, out_H, out_W) buffer (the logits) and out's geometry is ignored.
+ * res.d == NULL: no residual.                                                                                           */
+typedef struct rtm3d_vconv_desc {
+    rtm3d_vtensor in, out, res;
+    const float* d_w;
+    const float* d_bias;
+    int B, Hm, Wm, in_stride, out_scale, out_oy, out_ox;
+    int cin, cout, ntaps, relu;
+    int out_nchw_f32, out_H, out_W;
+    int tap_dy[RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_TAPS];
+} rtm3d_vconv_desc;
+int rtm3d_verify_conv_f32(void* stream, const rtm3d_vconv_desc* desc);
+
+/* rtm3d_op_maxpool in fp32 (same zero-border = -inf convention: pooled maps are post-ReLU).                             */
+int rtm3d_verify_maxpool_f32(void* stream, const rtm3d_vtensor* in, const rtm3d_vtensor* out, int B, int Ho, int Wo,
+                             int channels, int ksize, int stride, int pad);
+
+/* rtm3d_op_softmax_fuse in fp32: z_out = z_in + sum_i u_i * softmax_{H*W}(u_i), operands added in the given order
+ * (models/nets/keypoint_fpn_fusion.py:60-69); exp in fp32, the sums in fp64.  u: array of n_u <= 3 tensors;
+ * d_workspace: rtm3d_verify_softmax_workspace_bytes(B, C, n_u) bytes.                                                   */
+size_t rtm3d_verify_softmax_workspace_bytes(int B, int C, int n_u);
+int rtm3d_verify_softmax_fuse_f32(void* stream, const rtm3d_vtensor* z_in, const rtm3d_vtensor* z_out, int n_u,
+                                  const rtm3d_vtensor* u, int B, int H, int W, int C, void* d_workspace);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_GROUPS, MAX_TAPS = 4, 49
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -31,6 +31,23 @@ class ConvDesc(ctypes.Structure):
         ('kernel', c_int), ('bn_tile', c_int),
         ('out_nchw_f32', c_int), ('out_H', c_int), ('out_W', c_int),
         ('softmax_stat_slot', c_int),
+    ]
+
+
+class VTensor(ctypes.Structure):
+    """Mirror of struct rtm3d_vtensor (fp32 verification executor)."""
+    _fields_ = [('d', c_void_p), ('Hp', c_int), ('Wp', c_int), ('C', c_int), ('P', c_int), ('coff', c_int)]
+
+
+class VConvDesc(ctypes.Structure):
+    """Mirror of struct rtm3d_vconv_desc."""
+    _fields_ = [
+        ('inp', VTensor), ('out', VTensor), ('res', VTensor),
+        ('d_w', c_void_p), ('d_bias', c_void_p),
+        ('B', c_int), ('Hm', c_int), ('Wm', c_int), ('in_stride', c_int), ('out_scale', c_int), ('out_oy', c_int), ('out_ox', c_int),
+        ('cin', c_int), ('cout', c_int), ('ntaps', c_int), ('relu', c_int),
+        ('out_nchw_f32', c_int), ('out_H', c_int), ('out_W', c_int),
+        ('tap_dy', c_int * MAX_TAPS), ('tap_dx', c_int * MAX_TAPS),
     ]
 
 
@@ -76,6 +93,11 @@ SIGNATURES = {
     'rtm3d_stream_destroy': (c_int, [c_void_p]),
     'rtm3d_decode3d_scalar': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
+    'rtm3d_verify_conv_f32': (c_int, [c_void_p, ctypes.POINTER(VConvDesc)]),
+    'rtm3d_verify_maxpool_f32': (c_int, [c_void_p, ctypes.POINTER(VTensor), ctypes.POINTER(VTensor), c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_verify_softmax_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'rtm3d_verify_softmax_fuse_f32': (c_int, [c_void_p, ctypes.POINTER(VTensor), ctypes.POINTER(VTensor), c_int, ctypes.POINTER(VTensor),
+                                              c_int, c_int, c_int, c_int, c_void_p]),
     'rtm3d_decode3d_slots': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -69,6 +69,7 @@ class Model(object):
         self._plans = OrderedDict()
         self._ws = {}
         self._wcache = None
+        self._verify = None                      # (shape key, VerifyPlanF32) of forward_logits_fp32
         self.use_graph = None                    # None: automatic (hipGraph replay for batches <= GRAPH_MAX_BATCH)
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
         self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant,
@@ -96,6 +97,7 @@ class Model(object):
                 new[k] = v.to(torch.int64) if k.endswith('num_batches_tracked') else v.to(torch.float32).contiguous()
         self._sd = new
         self._wcache = None              # folded / packed weights belong to the old state dict
+        self._verify = None
         self._drop_plans()
         return None
 
@@ -202,6 +204,29 @@ class Model(object):
             plan.forward(torch.cuda.current_stream(dev).cuda_stream, xptr, ptrs)
         return tuple(outs)
 
+    def forward_logits_fp32(self, x):
+        """VERIFICATION mode (SURVEY.md H2 ii): the same recorded plan executed on fp32 tensors with fp32 weights and fp64
+        accumulation by ``rtm3d_amd.verify.VerifyPlanF32`` (simple HIP kernels, about 100x slower than forward_logits).
+        Feeding these logits to ``decode2d`` / ``decode3d_slots`` compares the device path with the reference's fp32 CPU path
+        without the fp16 storage error; ``forward`` never takes this path.  One executor is kept (the last shape used): its
+        activation workspace is twice the fp16 plan's, so verify on a few images, not on the benchmark batch."""
+        from .verify import VerifyPlanF32
+        x = self._check_input(x)
+        B, _, H, W = x.shape
+        key = (B, H, W, x.device.index)
+        if self._verify is None or self._verify[0] != key:
+            self._verify = None                     # free the previous executor's buffers first
+            if self._wcache is None:
+                self._wcache = WeightCache(self._sd)
+            ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache,
+                                     num_classes=self._num_classes)
+            self._verify = (key, VerifyPlanF32(ir, x.device))
+        return self._verify[1].forward(x, self._head_channels)
+
+    def release_verify(self):
+        """Free the fp32 verification executor's device buffers."""
+        self._verify = None
+
     def forward(self, x):
         pred_logits = self.forward_logits(x)
         if self.training:
@@ -285,11 +310,13 @@ class Model(object):
                 'vertex_offset_logits': logits[3]}
 
     # ------------------------------------------------------------------ fused device pipeline
-    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0)):
+    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), fp32_verify=False):
         """forward + 2D decode + 3D decode, all stream-ordered on the device (no host sync).
-        K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D)."""
+        K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D, logits).
+        fp32_verify=True: the network runs in the fp32 verification mode (forward_logits_fp32), the decode kernels are the
+        product's own."""
         from .model_utils import decode3d_slots, decode_smoke_slots
-        logits = self.forward_logits(x)
+        logits = self.forward_logits_fp32(x) if fp32_verify else self.forward_logits(x)
         det = self.decode2d(logits)
         dim_ref = dim_ref if dim_ref is not None else self.config.DETECTOR.dim_ref
         if len(dim_ref) < self._num_classes:

@@ -1,0 +1,136 @@
+"""fp32 verification executor of a plan (SURVEY.md H2 regime ii; include/rtm3d_hip.h "fp32 verification executor").
+
+The product path (``plan.RealizedPlan`` -> ``rtm3d_forward``) stores activations and weights in fp16.  ``VerifyPlanF32``
+replays the SAME ``plan.Plan`` - the op list ``build_plan`` records before any kernel is chosen: tap tables, channel
+slices instead of ``torch.cat``, sub-pixel phases of the transposed convolutions, folded BatchNorm, composed 1x1 pairs -
+on padded NHWC fp32 tensors through ``rtm3d_verify_{conv,maxpool,softmax_fuse}_f32`` (fp32 weights, fp64 accumulation).
+Its logits fed to the product's own ``rtm3d_decode2d`` / ``rtm3d_decode3d_slots`` give the end-to-end answer to
+"do the device's boxes match the reference's fp32 CPU path" (models/model.py:20-27 -> :29-75 ->
+utils/model_utils.py:264-312) without the fp16 storage error in the way.
+
+Verification only: about a hundred times slower than the MFMA path, used by ``Model.forward_logits_fp32``, the parity
+tests and ``bench.py``'s ``parity`` block; ``Model.forward`` never takes it.  PyTorch only owns the device buffers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class VerifyPlanF32(object):
+    def __init__(self, plan, device):
+        self.lib = _lib.load()
+        self.plan = plan
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('VerifyPlanF32 runs on an AMD GPU only; the CPU interpreter of the plan is tests/plan_interp.py')
+        B = plan.B
+        with torch.cuda.device(self.device):
+            # zero borders are written once here and never touched by the kernels (they implement the zero padding)
+            self.bufs = [torch.zeros(B, t['H'] + 2 * t['pad'], t['W'] + 2 * t['pad'], t['C'], dtype=torch.float32, device=self.device)
+                         for t in plan.tensors]
+            self._w = {}
+            for k, op in enumerate(plan.ops):
+                if op['op'] == 'conv':
+                    # (groups, taps, cout, cin) -> per group [taps][cin][cout]
+                    self._w[k] = [(self._dev(np.ascontiguousarray(op['w'][g].transpose(0, 2, 1))), self._dev(op['bias'][g]))
+                                  for g in range(op['groups'])]
+                elif op['op'] == 'headout':
+                    ws = []
+                    for w, b in zip(op['w'], op['bias']):
+                        co, ci = w.shape[0], w.shape[1]
+                        ws.append((self._dev(np.ascontiguousarray(w.reshape(co, ci, 9).transpose(2, 1, 0))), self._dev(b)))
+                    self._w[k] = ws
+            self._ws = None
+
+    def _dev(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+
+    def _vt(self, s):
+        t = self.plan.tensors[s.tid]
+        v = _lib.VTensor()
+        v.d = self.bufs[s.tid].data_ptr()
+        v.Hp, v.Wp, v.C, v.P, v.coff = t['H'] + 2 * t['pad'], t['W'] + 2 * t['pad'], t['C'], t['pad'], s.coff
+        return v
+
+    def forward(self, x, head_channels):
+        """x: (B, 3, H, W) fp32 CUDA tensor -> tuple of fp32 NCHW logit maps (models/model.py:21-23)."""
+        P, lib = self.plan, self.lib
+        B = P.B
+        if tuple(x.shape) != (B, 3, P.H, P.W) or not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError('VerifyPlanF32.forward: expected a (%d, 3, %d, %d) fp32 CUDA tensor' % (B, P.H, P.W))
+        dev = self.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            outs = [torch.empty(B, c, P.H // 4, P.W // 4, dtype=torch.float32, device=dev) for c in head_channels]
+            for k, op in enumerate(P.ops):
+                kind = op['op']
+                if kind == 'input4':
+                    o = op['out']
+                    t = P.tensors[o.tid]
+                    pad = t['pad']
+                    # layout change only (NCHW -> the NHWC4 operand of the stem, 4th channel stays zero)
+                    self.bufs[o.tid][:, pad:pad + t['H'], pad:pad + t['W'], 0:3] = x.permute(0, 2, 3, 1)
+                elif kind == 'conv':
+                    for g in range(op['groups']):
+                        d = _lib.VConvDesc()
+                        d.inp = self._vt(op['inp'][g])
+                        if op['out_nchw']:
+                            d.out.d = outs[op['out_nchw'] - 1].data_ptr()
+                            d.out_nchw_f32, d.out_H, d.out_W = 1, op['out_hw'][0], op['out_hw'][1]
+                        else:
+                            d.out = self._vt(op['out'][g])
+                        if op['res'][g] is not None:
+                            d.res = self._vt(op['res'][g])
+                        w, b = self._w[k][g]
+                        d.d_w, d.d_bias = w.data_ptr(), b.data_ptr()
+                        d.B, d.Hm, d.Wm, d.in_stride, d.out_scale = B, op['Hm'], op['Wm'], op['in_stride'], op['out_scale']
+                        d.out_oy, d.out_ox = op['out_off'][g]
+                        d.cin, d.cout, d.ntaps, d.relu = op['cin'], op['cout'], len(op['taps'][g]), int(bool(op['relu']))
+                        for t, (dy, dx) in enumerate(op['taps'][g]):
+                            d.tap_dy[t], d.tap_dx[t] = dy, dx
+                        _lib.check(lib.rtm3d_verify_conv_f32(stream, ctypes.byref(d)), 'verify_conv_f32(%s)' % op['name'])
+                elif kind == 'headout':
+                    taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+                    for h, (w, b) in enumerate(self._w[k]):
+                        d = _lib.VConvDesc()
+                        d.inp = self._vt(op['inp'])
+                        d.inp.coff = op['inp'].coff + h * 256
+                        d.out.d = outs[h].data_ptr()
+                        d.out_nchw_f32, d.out_H, d.out_W = 1, P.H // 4, P.W // 4
+                        d.d_w, d.d_bias = w.data_ptr(), b.data_ptr()
+                        d.B, d.Hm, d.Wm, d.in_stride, d.out_scale = B, P.H // 4, P.W // 4, 1, 1
+                        d.cin, d.cout, d.ntaps, d.relu = 256, int(w.shape[2]), 9, 0
+                        for t, (dy, dx) in enumerate(taps):
+                            d.tap_dy[t], d.tap_dx[t] = dy, dx
+                        _lib.check(lib.rtm3d_verify_conv_f32(stream, ctypes.byref(d)), 'verify_conv_f32(%s)' % op['name'])
+                elif kind == 'maxpool':
+                    i, o = self._vt(op['inp']), self._vt(op['out'])
+                    Ho, Wo = P.dims(op['out'])
+                    _lib.check(lib.rtm3d_verify_maxpool_f32(stream, ctypes.byref(i), ctypes.byref(o), B, Ho, Wo, op['inp'].C,
+                                                            op['k'], op['stride'], op['pad']), 'verify_maxpool_f32')
+                elif kind == 'softmax':
+                    zi, zo = self._vt(op['z_in']), self._vt(op['z_out'])
+                    n_u = len(op['us'])
+                    us = (_lib.VTensor * 3)()
+                    for j, u in enumerate(op['us']):
+                        us[j] = self._vt(u)
+                    H, W = P.dims(op['z_in'])
+                    C = op['z_in'].C
+                    need = int(lib.rtm3d_verify_softmax_workspace_bytes(B, C, n_u))
+                    if self._ws is None or self._ws.numel() < need:
+                        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    _lib.check(lib.rtm3d_verify_softmax_fuse_f32(stream, ctypes.byref(zi), ctypes.byref(zo), n_u, us, B, H, W, C,
+                                                                 self._ws.data_ptr()), 'verify_softmax_fuse_f32')
+                else:
+                    raise AssertionError('VerifyPlanF32: unknown op %r' % kind)
+        return tuple(outs)
+
+    def fetch(self, name):
+        """Stage output by its plan name (e.g. 'z', 'feat3') as fp32 NCHW, for parity tests."""
+        s = self.plan.named[name]
+        t = self.plan.tensors[s.tid]
+        pad = t['pad']
+        return self.bufs[s.tid][:, pad:pad + t['H'], pad:pad + t['W'], s.coff:s.coff + s.C].permute(0, 3, 1, 2).contiguous()
