@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
     ap.add_argument('--v2-min-tiles', type=int, default=None, help='DIAGNOSTIC: fewest 256x256 tiles a layer needs to go to the persistent conv256 kernel (plan.V2_MIN_TILES)')
+    ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
 
@@ -334,6 +335,8 @@ def main():
     sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
     model = rtm3d_amd.create_model(cfg).to(dev).eval()
     model.load_state_dict(sd)
+    if args.graph:
+        model.use_graph = True
     # this rank's shard of the global synthetic batch (image b uses seed 1234+b: rank independent)
     x = weights.synth_images(B, H, W, seed=1234, first=rank * B).to(dev)
     K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
@@ -362,10 +365,12 @@ def main():
     plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
     info = plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
     dom = max(range(len(info)), key=lambda i: info[i]['ms'])
-    plan.probe_set(dom)
+    if not args.graph:
+        plan.probe_set(dom)
     for _ in range(max(0, args.warmup - 1)):
         step()
-    plan.probe_set(dom)                         # reset the probe ring: only timed steps are averaged
+    if not args.graph:
+        plan.probe_set(dom)                     # reset the probe ring: only timed steps are averaged
 
     def fence():
         if pipe is not None:
@@ -393,7 +398,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         multi = {'per_rank_ms_per_step': [round(v / args.steps * 1e3, 3) for v in allt.tolist()]}
-    dom_ms, dom_n = plan.probe_read()
+    dom_ms, dom_n = plan.probe_read() if not args.graph else (info[dom]['ms'], 0)
     n_det = det.n.sum().item()
     if pipe is not None:
         rec = pipe.results(rec)
@@ -448,6 +453,8 @@ def main():
             out['DIAGNOSTIC_v2_min_tiles'] = args.v2_min_tiles
         if args.no_conv128:
             out['DIAGNOSTIC_no_conv128'] = True
+        if args.graph:
+            out['DIAGNOSTIC_graph'] = 'hipGraph replay; roofline.launch_ms from the per-op pass, not from the timed region'
         if args.heat_bias is not None:
             out['DIAGNOSTIC'] = 'heat-map bias overridden to %g (not the benchmark workload)' % args.heat_bias
         if args.per_op:
