@@ -234,6 +234,54 @@ def test_all_gather_records_gloo_world3_uneven_shards():
     assert all(ok for _, ok, _ in res) and len(set(s for _, _, s in res)) == 1
 
 
+def _gloo_config3_worker(rank, world, port, q):
+    """BASELINE config[3] geometry: 256 images = 8 ranks x 32, top-100 records of 32 floats (410 KB per rank, 3.3 MB gathered);
+    image g carries (g * 7) % 101 detections whose score encodes (g, slot), so any mis-ordered block shows."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    total, topk = 256, 100
+    lo, hi, per = rdist.padded_shard(total, rank, world)
+    assert (lo, hi, per) == (rank * 32, rank * 32 + 32, 32) == rdist.shard_range(total, rank, world) + (32,)
+    rec = torch.zeros(per, topk, rdist.RECORD)
+    for slot in range(per):
+        g = lo + slot
+        cnt = (g * 7) % 101
+        rec[slot, :cnt, 0] = g % 3
+        rec[slot, :cnt, 1] = (g * 128 + torch.arange(cnt)).float() / 65536.0           # exact in fp32
+        rec[slot, :cnt, 31] = 1.0
+    assert rec.numel() * 4 == 409600
+    allrec = rdist.trim_gathered(rdist.all_gather_records(rec, check_shapes=True), total)
+    assert allrec.shape == (total, topk, rdist.RECORD) and torch.equal(allrec[lo:hi], rec)
+    un = rdist.unpack_records(allrec)
+    for g in range(total):
+        cnt = (g * 7) % 101
+        if cnt == 0:
+            assert un[g] is None
+            continue
+        assert len(un[g]['cls']) == cnt and int(un[g]['cls'][0]) == g % 3
+        assert torch.equal(un[g]['score'], (g * 128 + torch.arange(cnt)).float() / 65536.0)
+    q.put((rank, float(allrec.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_all_gather_records_gloo_world8_config3_geometry():
+    """The collective of the 8-GPU configuration (bs = 256 sharded 8 x 32), rehearsed on CPU ranks over gloo: contiguous
+    shards, ONE all_gather_into_tensor of (32, 100, 32) fp32 per rank, results ordered by global image index on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    ps = [ctx.Process(target=_gloo_config3_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(q.get() for _ in range(8))
+    assert len(res) == 8 and len(set(res.values())) == 1
+
+
 def test_box_projection_matches_reference_golden_vectors():
     """n3: rotation_matrix / create_corners / calc_proj_corners against the vectors produced by running the
     reference (tests/golden/make_golden_project.py), incl. yaw values inside its 1e-3 snapping window."""
