@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument('--diag-no-decode3d', action='store_true', help='DIAGNOSTIC ONLY: skip the 3D decode (result is not a valid benchmark)')
     ap.add_argument('--heat-bias', type=float, default=None, help='override the synthetic heat-map bias (e.g. +2: top-k saturates, 100 objects/image; marks the line DIAGNOSTIC)')
     ap.add_argument('--v2-min-tiles', type=int, default=None, help='DIAGNOSTIC: fewest 256x256 tiles a layer needs to go to the persistent conv256 kernel (plan.V2_MIN_TILES)')
+    ap.add_argument('--from-uint8', action='store_true', help='row n1 measured: every step starts from B uint8 360x1240 camera-style images resident in HBM (Resize to 1280 + letterbox + normalise on the device, two launches, straight into the fp16 input tensor) instead of the fp32 NCHW batch')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     return ap.parse_args()
@@ -348,7 +349,22 @@ def main():
     if pipe is not None and use_dist:
         pipe.time_gather = True                 # event pair around the collective on the side stream (diagnostics)
 
+    imgs_u8 = None
+    if args.from_uint8:
+        if pipe is None or (H, W) != (384, 1280):
+            raise SystemExit('--from-uint8 needs the pipelined 384x1280 configuration')
+        from rtm3d_amd import preprocess
+        gen = torch.Generator().manual_seed(4321 + rank)
+        imgs_u8 = [torch.randint(0, 256, (360, 1240, 3), generator=gen, dtype=torch.uint8).to(dev) for _ in range(B)]
+        rhw = preprocess.resized_size(360, 1240, 1280)
+        K0 = preprocess.resize_K(weights.synth_intrinsics(), (360, 1240), rhw)
+        K0 = preprocess.adjust_K(K0, (W - rhw[1]) // 2, (H - rhw[0]) // 2)
+        K = torch.as_tensor(np.tile(K0, (B, 1)), dtype=torch.float64, device=dev)
+
     def step():
+        if imgs_u8 is not None:                     # n1 in front: uint8 images -> Resize + letterbox + normalise -> plan
+            i = pipe.submit_uint8(imgs_u8, K, (H, W), resize_to=1280)
+            return i, pipe.det[i % pipe.depth]
         if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
             i = pipe.submit(x, K)
             return i, pipe.det[i % pipe.depth]
@@ -453,6 +469,9 @@ def main():
             out['DIAGNOSTIC_v2_min_tiles'] = args.v2_min_tiles
         if args.no_conv128:
             out['DIAGNOSTIC_no_conv128'] = True
+        if args.from_uint8:
+            out['config']['input'] = 'B uint8 360x1240x3 images in HBM -> Resize(1280, bilinear) + letterbox + normalise on the device (rtm3d_preprocess_batch, fp16 NHWC4 output) in every step'
+            out['NOTE'] = 'row n1 measurement, not the BASELINE line (whose input is the normalised fp32 batch)'
         if args.graph:
             out['DIAGNOSTIC_graph'] = 'hipGraph replay; roofline.launch_ms from the per-op pass, not from the timed region'
         if args.heat_bias is not None:
@@ -468,7 +487,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, cfg, full=args.cpu_full)
         else:
             out['cpu_baseline'] = None
-        if not args.no_parity and world == 1:
+        if not args.no_parity and world == 1 and not args.from_uint8:
             out['parity'] = parity_check(model, cfg, sd, bb, x, args.parity_images, dev)
         else:
             out['parity'] = None

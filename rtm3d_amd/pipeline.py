@@ -81,6 +81,22 @@ class Detect3DPipeline(object):
         prio = int(prio) if prio is not None else (-1 if n_side == 1 else 0)
         return torch.cuda.Stream(device=self.dev, priority=prio)
 
+    def submit_uint8(self, images, K_per_image, size, resize_to=None):
+        """The same step fed by camera images: ``images`` = list of B uint8 (h, w, 3) CUDA tensors of any
+        sizes; Resize (longest side -> resize_to) + letterbox into the (H, W) canvas + normalise run as two launches that
+        write the network's own fp16 NHWC4 input tensor (rtm3d_amd.preprocess.preprocess_batch), then the plan is replayed
+        on it.  K_per_image must already carry the Resize / padding bookkeeping (preprocess.resize_K / adjust_K)."""
+        from . import preprocess
+        if len(images) != self.B:
+            raise ValueError('Detect3DPipeline was built for batches of %d images, got %d' % (self.B, len(images)))
+        cfg = self.model.config
+        H, W = int(size[0]), int(size[1])
+
+        def feed():
+            preprocess.preprocess_batch(images, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=resize_to, model=self.model)
+            return self.model.forward_logits(None, preloaded=(self.B, H, W))
+        return self._submit(feed, K_per_image)
+
     def submit(self, x, K_per_image):
         """Enqueue one batch; returns its step index.  Asynchronous."""
         if x.dim() != 4 or x.shape[0] != self.B:
@@ -89,6 +105,9 @@ class Detect3DPipeline(object):
             # rtm3d_amd.distributed.padded_shard)
             raise ValueError('Detect3DPipeline was built for batches of %d images, got input of shape %s'
                              % (self.B, tuple(x.shape)))
+        return self._submit(lambda: self.model.forward_logits(x), K_per_image)
+
+    def _submit(self, run_network, K_per_image):
         if not isinstance(K_per_image, torch.Tensor) or K_per_image.numel() != self.B * 9 or not K_per_image.is_cuda:
             raise ValueError('K_per_image must be a CUDA tensor with %d x 9 intrinsics' % self.B)
         i = self.count
@@ -96,7 +115,7 @@ class Detect3DPipeline(object):
         main = torch.cuda.current_stream(self.dev)
         if i >= self.depth:
             main.wait_event(self.ev_b[s])                 # slot s is free again
-        logits = self.model.forward_logits(x)
+        logits = run_network()
         self.model.decode2d(logits, out=self.det[s])
         self.ev_a[s].record(main)
         side = self.sides[s % len(self.sides)]

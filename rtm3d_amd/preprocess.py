@@ -31,6 +31,22 @@ def normalize_lut(mean, std):
     return np.ascontiguousarray(((v - m) / s).astype(np.float32))
 
 
+_LUTS = {}
+
+
+def device_luts(mean, std, dev):
+    """(fp32 LUT, fp16 LUT) on the device, cached per (mean, std, device): building them per call would put a pageable
+    host->device copy (which blocks the host and serialises streams) in front of every batch."""
+    key = (tuple(float(v) for v in mean), tuple(float(v) for v in std), dev.index)
+    hit = _LUTS.get(key)
+    if hit is None:
+        lut = normalize_lut(mean, std)
+        with torch.cuda.device(dev):
+            hit = (torch.as_tensor(lut, device=dev), torch.as_tensor(lut.astype(np.float16), device=dev))   # round-to-nearest-even, as the device cast
+        _LUTS[key] = hit
+    return hit
+
+
 def letterbox_normalize(images, size, mean, std, out=None):
     """images: list of uint8 CUDA tensors (h, w, 3); size = (H, W).  Returns ((B,3,H,W) fp32 CUDA tensor,
     [(pad_w, pad_h)] per image)."""
@@ -110,10 +126,8 @@ def preprocess_batch(images, size, mean, std, resize_to=None, out=None, model=No
     if (rhw[:, 0] > H).any() or (rhw[:, 1] > W).any() or (rhw < 1).any():
         raise ValueError('a resized image does not fit the %dx%d canvas: %s' % (H, W, rhw.tolist()))
     ptrs = (ctypes.c_void_p * B)(*[i.data_ptr() for i in imgs])
-    lut = normalize_lut(mean, std)
+    d_lut, d_lut16 = device_luts(mean, std, dev)
     with torch.cuda.device(dev):
-        d_lut = torch.as_tensor(lut, device=dev)
-        d_lut16 = torch.as_tensor(lut.astype(np.float16), device=dev)       # round-to-nearest-even, as the device cast
         sums = torch.zeros(B, 3, dtype=torch.int64, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if model is not None:

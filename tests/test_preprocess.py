@@ -138,3 +138,31 @@ def test_hip_preprocess_batch_vs_oracle_and_network_input():
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         preprocess.preprocess_batch([torch.zeros(200, 10, 3, dtype=torch.uint8).cuda()], (128, 320), mean, std)
+
+
+@pytest.mark.gpu
+def test_pipeline_submit_uint8_equals_fp32_feed():
+    """Detect3DPipeline.submit_uint8 (camera images -> Resize + letterbox + normalise -> plan, n1 in front of the path) gives
+    the records of the same batch fed as the reference's fp32 NCHW tensor, bit for bit, over several pipelined steps."""
+    import rtm3d_amd
+    from rtm3d_amd import preprocess, weights
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    bb = 'RESNET-18'
+    cfg = rtm3d_amd.kitti_config(bb)
+    dev = torch.device('cuda', 0)
+    m = rtm3d_amd.create_model(cfg).to(dev).eval()
+    m.load_state_dict(weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5))
+    rng = np.random.Generator(np.random.PCG64(10))
+    H, W, B = 128, 256, 3
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
+    pipe_a = Detect3DPipeline(m, B, dev, gather=False)
+    pipe_b = Detect3DPipeline(m, B, dev, gather=False)
+    for step in range(3):
+        imgs = [torch.from_numpy(rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)).to(dev) for hh, ww in ((180, 500), (100, 256), (120, 300))]
+        x32, _, _ = preprocess.preprocess_batch(imgs, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=256)
+        ra = pipe_a.results(pipe_a.submit(x32, K)).clone()
+        rb = pipe_b.results(pipe_b.submit_uint8(imgs, K, (H, W), resize_to=256)).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ra, rb) and float(ra[:, :, 31].sum()) > 0
+    with pytest.raises(ValueError):
+        pipe_b.submit_uint8(imgs[:2], K, (H, W), resize_to=256)
