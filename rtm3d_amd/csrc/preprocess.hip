@@ -114,19 +114,25 @@ __device__ __forceinline__ void pre_store(void* out, int b, int y, int x, int H,
     }
 }
 
-// interior: a workgroup walks rows of the resized image (grid.x strides the rows, grid.y = image).  The column coefficients
-// (source column, a0, a1) depend on x only: computed once per workgroup into LDS (8 bytes per column; the first form of this
-// kernel redid the fp64 coordinate arithmetic and an integer division per pixel and ran at 1.1 TB/s: 0.146 ms for 32 images
-// of 360 x 1240 -> 371 x 1280); the row coefficients are uniform per row; the fp16 table sits in LDS.  Per-image channel
-// sums via LDS + 3 atomics per block.
+// interior: a workgroup takes bands of `band_rows` consecutive rows of the resized image (grid.x strides the bands, grid.y =
+// image).  Per workgroup, once: the column coefficients (source column, a0, a1 - they depend on x only) and the fp16 table
+// go to LDS.  Per band: the source rows it needs are ONE contiguous byte span of the HWC image; it is copied to LDS with
+// 16-byte loads (head / tail bytes singly, nothing outside the image is touched) and the 12 byte-gathers per output pixel
+// read LDS instead of global memory; the row coefficients are uniform per row.  Per-image channel sums via LDS + 3
+// atomics per block.  History (32 images 360 x 1240 -> 371 x 1280, fp16 NHWC4 out): one thread per pixel redoing the
+// fp64 coordinate arithmetic and an integer division 0.146 ms; column table 0.102 ms; + staged source rows: see
+// profiles/r02_n1_input_path.txt.  A band whose source span does not fit the stage (very wide images) gathers from
+// global memory as before.
 template <int MODE>
 __global__ __launch_bounds__(256) void pre_interior_kernel(const PreBatch pb, void* __restrict__ out, int H, int W, int P,
                                                           const float* __restrict__ lut, const f16* __restrict__ lut16,
-                                                          unsigned long long* __restrict__ sums) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pre_dyn[];     // [rw] int2 (x0, a0 | a1 << 16)
+                                                          unsigned long long* __restrict__ sums, int band_rows, int col_bytes,
+                                                          int stage_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_dyn[];     // [rw] int2 (x0, a0 | a1 << 16), then the stage
     __shared__ f16 lut_s[768];
     __shared__ unsigned int sh[3][256];
     int2* const col = (int2*)pre_dyn;
+    unsigned char* const stage = pre_dyn + col_bytes;
     const int b = blockIdx.y;
     const int rh = pb.rh[b], rw = pb.rw[b], h = pb.h[b], w = pb.w[b];
     const uint8_t* __restrict__ img = pb.img[b];
@@ -134,45 +140,70 @@ __global__ __launch_bounds__(256) void pre_interior_kernel(const PreBatch pb, vo
     const int pad_h = (H - rh) / 2, pad_w = (W - rw) / 2;
     const bool same = rh == h && rw == w;
     if (MODE == 1) for (int i = threadIdx.x; i < 768; i += 256) lut_s[i] = lut16[i];
-    if (!same)
-        for (int x = threadIdx.x; x < rw; x += 256) {
-            int x0, x1, a0, a1;
-            resize_coef(x, sx_scale, w, x0, x1, a0, a1);
-            col[x] = make_int2(x0 | ((x1 - x0) << 30), a0 | (a1 << 16));           // x1 - x0 is 0 or 1; a0, a1 <= 2048
-        }
-    __syncthreads();
+    for (int x = threadIdx.x; x < rw; x += 256) {
+        int x0 = x, x1 = x, a0 = 2048, a1 = 0;
+        if (!same) resize_coef(x, sx_scale, w, x0, x1, a0, a1);
+        col[x] = make_int2(x0 | ((x1 - x0) << 30), a0 | (a1 << 16));               // x1 - x0 is 0 or 1; a0, a1 <= 2048
+    }
     unsigned int s0 = 0, s1 = 0, s2 = 0;
-    for (int y = blockIdx.x; y < rh; y += gridDim.x) {
-        int y0 = y, y1 = y, b0 = 2048, b1 = 0;
-        if (!same) resize_coef(y, sy_scale, h, y0, y1, b0, b1);
-        const uint8_t* __restrict__ r0p = img + (size_t)y0 * w * 3;
-        const uint8_t* __restrict__ r1p = img + (size_t)y1 * w * 3;
-        for (int x = threadIdx.x; x < rw; x += 256) {
-            unsigned int v0, v1, v2;
-            if (same) {
-                const uint8_t* sp = r0p + (size_t)x * 3;
-                v0 = sp[0]; v1 = sp[1]; v2 = sp[2];
-            } else {
+    const size_t pitch = (size_t)w * 3;
+    for (int r0 = blockIdx.x * band_rows; r0 < rh; r0 += gridDim.x * band_rows) {
+        const int r1 = min(r0 + band_rows, rh);
+        // source rows of the band: y0 of its first row .. y1 of its last
+        int ylo = r0, yhi = r1 - 1, t0, t1, t2;
+        if (!same) { resize_coef(r0, sy_scale, h, ylo, t0, t1, t2); resize_coef(r1 - 1, sy_scale, h, t0, yhi, t1, t2); }
+        const uint8_t* gs = img + (size_t)ylo * pitch;
+        const size_t len = (size_t)(yhi - ylo + 1) * pitch;
+        const int a0g = (int)((uintptr_t)gs & 15);
+        const bool staged = len + 15 <= (size_t)stage_bytes;
+        __syncthreads();                                   // column table written / previous band's reads done
+        if (staged) {
+            const uint8_t* ga = gs - a0g;                  // 16-byte aligned; chunk k covers ga + 16k .. + 15
+            const int nchunks = (int)((a0g + len + 15) >> 4);
+            for (int k = threadIdx.x; k < nchunks; k += 256) {
+                const uint8_t* c = ga + (size_t)k * 16;
+                if (c >= gs && c + 16 <= gs + len) {
+                    *(u32x4*)(stage + (size_t)k * 16) = *(const u32x4*)c;
+                } else {
+                    for (int j = 0; j < 16; ++j) if (c + j >= gs && c + j < gs + len) stage[(size_t)k * 16 + j] = c[j];
+                }
+            }
+            __syncthreads();
+        }
+        for (int y = r0; y < r1; ++y) {
+            int y0 = y, y1 = y, b0 = 2048, b1 = 0;
+            if (!same) resize_coef(y, sy_scale, h, y0, y1, b0, b1);
+            for (int x = threadIdx.x; x < rw; x += 256) {
                 const int2 c = col[x];
                 const int x0 = c.x & 0x3fffffff, dx3 = ((unsigned int)c.x >> 30) * 3;
                 const int a0 = c.y & 0xffff, a1 = (unsigned int)c.y >> 16;
-                const uint8_t* p0 = r0p + (size_t)x0 * 3;
-                const uint8_t* p1 = r1p + (size_t)x0 * 3;
                 unsigned int v[3];
+                if (staged) {
+                    const unsigned char* p0 = stage + a0g + (size_t)(y0 - ylo) * pitch + (size_t)x0 * 3;
+                    const unsigned char* p1 = stage + a0g + (size_t)(y1 - ylo) * pitch + (size_t)x0 * 3;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const int q0 = (int)p0[ch] * a0 + (int)p0[dx3 + ch] * a1;
-                    const int q1 = (int)p1[ch] * a0 + (int)p1[dx3 + ch] * a1;
-                    v[ch] = (unsigned int)((((b0 * (q0 >> 4)) >> 16) + ((b1 * (q1 >> 4)) >> 16) + 2) >> 2);
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const int q0 = (int)p0[ch] * a0 + (int)p0[dx3 + ch] * a1;
+                        const int q1 = (int)p1[ch] * a0 + (int)p1[dx3 + ch] * a1;
+                        v[ch] = same ? (unsigned int)p0[ch] : (unsigned int)((((b0 * (q0 >> 4)) >> 16) + ((b1 * (q1 >> 4)) >> 16) + 2) >> 2);
+                    }
+                } else {
+                    const uint8_t* p0 = img + (size_t)y0 * pitch + (size_t)x0 * 3;
+                    const uint8_t* p1 = img + (size_t)y1 * pitch + (size_t)x0 * 3;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const int q0 = (int)p0[ch] * a0 + (int)p0[dx3 + ch] * a1;
+                        const int q1 = (int)p1[ch] * a0 + (int)p1[dx3 + ch] * a1;
+                        v[ch] = same ? (unsigned int)p0[ch] : (unsigned int)((((b0 * (q0 >> 4)) >> 16) + ((b1 * (q1 >> 4)) >> 16) + 2) >> 2);
+                    }
                 }
-                v0 = v[0]; v1 = v[1]; v2 = v[2];
-            }
-            s0 += v0; s1 += v1; s2 += v2;
-            if (MODE == 0) {
-                pre_store<0>(out, b, y + pad_h, x + pad_w, H, W, P, lut, lut16, v0, v1, v2);
-            } else {
-                const f16x4 px = {lut_s[v0], lut_s[256 + v1], lut_s[512 + v2], (f16)0.f};
-                *(f16x4*)((f16*)out + (((size_t)b * (H + 2 * P) + y + pad_h + P) * (W + 2 * P) + x + pad_w + P) * 4) = px;
+                s0 += v[0]; s1 += v[1]; s2 += v[2];
+                if (MODE == 0) {
+                    pre_store<0>(out, b, y + pad_h, x + pad_w, H, W, P, lut, lut16, v[0], v[1], v[2]);
+                } else {
+                    const f16x4 px = {lut_s[v[0]], lut_s[256 + v[1]], lut_s[512 + v[2]], (f16)0.f};
+                    *(f16x4*)((f16*)out + (((size_t)b * (H + 2 * P) + y + pad_h + P) * (W + 2 * P) + x + pad_w + P) * 4) = px;
+                }
             }
         }
     }
@@ -218,7 +249,8 @@ extern "C" int rtm3d_preprocess_batch(void* stream, int B, const uint8_t* const*
     for (int b0 = 0; b0 < B; b0 += PRE_MAX_BATCH) {
         const int nb = B - b0 < PRE_MAX_BATCH ? B - b0 : PRE_MAX_BATCH;
         PreBatch pb;
-        int max_in = 0, max_border = 0, max_rh = 0, max_rw = 0;
+        int max_border = 0, max_rh = 0, max_rw = 0, max_w = 0;
+        double max_scale = 0.0;
         for (int i = 0; i < nb; ++i) {
             const int h = h_hw[2 * (b0 + i)], w = h_hw[2 * (b0 + i) + 1];
             const int rh = h_resized_hw ? h_resized_hw[2 * (b0 + i)] : h, rw = h_resized_hw ? h_resized_hw[2 * (b0 + i) + 1] : w;
@@ -227,22 +259,31 @@ extern "C" int rtm3d_preprocess_batch(void* stream, int B, const uint8_t* const*
                 return 1;
             }
             pb.img[i] = h_imgs[b0 + i]; pb.h[i] = h; pb.w[i] = w; pb.rh[i] = rh; pb.rw[i] = rw;
-            max_in = rh * rw > max_in ? rh * rw : max_in;
-            max_rh = rh > max_rh ? rh : max_rh; max_rw = rw > max_rw ? rw : max_rw;
+            max_rh = rh > max_rh ? rh : max_rh; max_rw = rw > max_rw ? rw : max_rw; max_w = w > max_w ? w : max_w;
+            max_scale = (double)h / rh > max_scale ? (double)h / rh : max_scale;
             max_border = H * W - rh * rw > max_border ? H * W - rh * rw : max_border;
         }
         // offsets of this sub-batch in the outputs
         void* o = out_mode == 0 ? (void*)((float*)d_out + (size_t)b0 * 3 * H * W)
                                 : (void*)((f16*)d_out + (size_t)b0 * (H + 2 * out_border) * (W + 2 * out_border) * 4);
         unsigned long long* sm = d_sums + (size_t)b0 * 3;
-        // a workgroup takes every bx-th row of its image: about 8 workgroups per CU over the sub-batch, at least 4 rows each
+        // bands of rows per workgroup: the stage holds (band_rows * scale + 2) source rows of the widest image; 48 KB of stage
+        // leave room for two workgroups per CU.  About 8 workgroups per CU over the sub-batch.
+        const int col_bytes = (int)(((size_t)max_rw * sizeof(int2) + 15) & ~(size_t)15);
+        if (col_bytes > 60000) { rt_set_error("preprocess_batch: resized width %d exceeds the kernel's column table", max_rw); return 1; }
+        int stage_bytes = 64 * 1024 - 8 * 1024 - col_bytes;            // total dynamic + static LDS stays under 64 KB
+        stage_bytes = stage_bytes < 0 ? 0 : (stage_bytes > 48 * 1024 ? 48 * 1024 : stage_bytes);
+        const size_t row_bytes = (size_t)max_w * 3;
+        const int cap_rows = (int)((stage_bytes > 15 ? stage_bytes - 15 : 0) / (row_bytes ? row_bytes : 1));
+        int band_rows = (int)((cap_rows - 2) / (max_scale > 1.0 ? max_scale : 1.0));
+        band_rows = band_rows < 1 ? 1 : (band_rows > 16 ? 16 : band_rows);
         int bx = (2048 + nb - 1) / nb;
-        bx = bx > (max_rh + 3) / 4 ? (max_rh + 3) / 4 : bx;
+        const int bands = (max_rh + band_rows - 1) / band_rows;
+        bx = bx > bands ? bands : bx;
         bx = bx < 1 ? 1 : bx;
-        const size_t dyn = (size_t)max_rw * sizeof(int2);
-        if (dyn > 60000) { rt_set_error("preprocess_batch: resized width %d exceeds the kernel's column table", max_rw); return 1; }
-        if (out_mode == 0) hipLaunchKernelGGL(pre_interior_kernel<0>, dim3(bx, nb), dim3(256), dyn, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
-        else hipLaunchKernelGGL(pre_interior_kernel<1>, dim3(bx, nb), dim3(256), dyn, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm);
+        const size_t dyn = (size_t)col_bytes + stage_bytes;
+        if (out_mode == 0) hipLaunchKernelGGL(pre_interior_kernel<0>, dim3(bx, nb), dim3(256), dyn, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm, band_rows, col_bytes, stage_bytes);
+        else hipLaunchKernelGGL(pre_interior_kernel<1>, dim3(bx, nb), dim3(256), dyn, s, pb, o, H, W, out_border, d_lut, (const f16*)d_lut16, sm, band_rows, col_bytes, stage_bytes);
         if (max_border > 0) {
             int gx = (max_border + 255) / 256;
             gx = gx > 256 ? 256 : gx;
