@@ -70,6 +70,9 @@ class Plan(object):
         Hm, Wm = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
         if out is not None:
             assert out.C == cout and self.dims(out) == (Hm, Wm), (name, out.C, cout, self.dims(out), (Hm, Wm))
+            # a residual must not alias the output: the kernels pad a partial pixel tile with copies of its last pixel ("a
+            # same-value write"), and a copy that loads the residual after another copy has stored would add it twice
+            assert res is None or res.tid != out.tid or res.coff + res.C <= out.coff or out.coff + out.C <= res.coff, (name, 'residual aliases the output')
         self.ops.append({'op': 'conv', 'name': name, 'inp': [inp], 'out': [out], 'res': [res], 'Hm': Hm, 'Wm': Wm,
                          'in_stride': stride, 'out_scale': 1, 'cin': cin, 'cout': cout, 'groups': 1,
                          'taps': [taps], 'out_off': [(0, 0)], 'relu': relu, 'w': wt.astype(np.float32),
