@@ -174,6 +174,10 @@ int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_f
  * L-BFGS-B (m=10, factr=1e7, pgtol=1e-5, maxls=20, unbounded) started at
  * [0,1,l_ref,h_ref,w_ref,ref_loc].  Replaces optim_decode_bbox3d, utils/model_utils.py:264-312
  * (objective :155-177, gradient :206-234) and scipy.optimize.minimize(method='L-BFGS-B').
+ * Iteration driver, More'-Thuente line search, BFGS skip rule and stopping tests follow L-BFGS-B 3.0 step by step; the
+ * search direction -B^-1 g of the unbounded case is computed by the two-loop recursion over the stored pairs instead of the
+ * published subspace step (formk / subsm) - the same vector in exact arithmetic, a third of the dependent fp64 operations
+ * (rtm3d_amd/csrc/lbfgsb.h; rtm3d_decode3d_reference_form below runs the published step for comparison).
  *   d_cls[N] int64, d_verts[N*16] fp32, d_K[N*9] fp64 (row-major 3x3 per object),
  *   d_dim_ref[ncls*3] fp64 (h,w,l), d_ref_loc[3] fp64.
  * Outputs: d_x[N*8] fp64 final iterate, d_fun[N] fp64, d_nit[N] int32, d_status[N] int32
@@ -248,11 +252,16 @@ int rtm3d_input_tensor(rtm3d_ctx* ctx, void** d_base, int* B, int* H, int* W, in
 int rtm3d_stream_create_cumask(int device, int n_cus, void** stream);
 int rtm3d_stream_destroy(void* stream);
 
-/* Cross-check entry: identical arguments and results to rtm3d_decode3d, computed by the
- * one-lane-per-object form of the solver (slow; used by the parity tests only).                     */
+/* Cross-check entries, identical arguments to rtm3d_decode3d, one lane per object (slow; parity tests only):
+ *   rtm3d_decode3d_scalar          the product's arithmetic: results bit-identical to rtm3d_decode3d;
+ *   rtm3d_decode3d_reference_form  L-BFGS-B 3.0 with its published subspace step (formk / subsm / formt), the form
+ *                                  scipy.optimize.minimize(method='L-BFGS-B') runs (utils/model_utils.py:295-296).              */
 int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                           const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                           double* d_fun, int32_t* d_nit, int32_t* d_status);
+int rtm3d_decode3d_reference_form(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                                  const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
+                                  double* d_fun, int32_t* d_nit, int32_t* d_status);
 
 /* ------------------------------------------------------------------ fp32 verification executor (regime ii)
  * The product path stores activations and weights in fp16; BASELINE's "3D-box L-inf vs CPU ref" through fp16 logits is

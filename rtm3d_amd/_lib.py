@@ -91,6 +91,8 @@ SIGNATURES = {
                                    ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_stream_create_cumask': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
     'rtm3d_stream_destroy': (c_int, [c_void_p]),
+    'rtm3d_decode3d_reference_form': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
     'rtm3d_decode3d_scalar': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     'rtm3d_verify_conv_f32': (c_int, [c_void_p, ctypes.POINTER(VConvDesc)]),

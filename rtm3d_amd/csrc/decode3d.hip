@@ -1,4 +1,6 @@
-// 3D box decode on device: one lane per detected object runs the fp64 L-BFGS-B of lbfgsb.h.
+// 3D box decode on device: the fp64 L-BFGS-B of lbfgsb.h, one wavefront per object (lbfgsb_wave.h, the product form: direct
+// two-loop search direction) or one lane per object (the cross-check kernels: the same direct form, bit-identical to the wave
+// kernel, and the published subspace form SciPy runs).
 // Replaces optim_decode_bbox3d (utils/model_utils.py:264-312) + scipy L-BFGS-B.
 // The work is latency-bound fp64 (a few hundred kFLOP per object, <= topk objects per image), so the
 // kernel only needs enough lanes in flight: 64-lane workgroups, objects spread over the CUs.
@@ -9,6 +11,7 @@
 
 // slot mode (n_per_image != nullptr): object i lives in slot (image = i / topk, rank = i % topk) of
 // the decode2d outputs, is valid iff rank < n_per_image[image], and uses K[image].
+template <int DIRECT>
 __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __restrict__ cls,
                                                       const float* __restrict__ verts, const double* __restrict__ K,
                                                       const double* __restrict__ dim_ref, int ncls,
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
     LbWork w;
     double f;
     int it;
-    const int st = lb_minimize(&p, x, &f, &it, &w, 15000, 15000);
+    const int st = lb_minimize(&p, x, &f, &it, &w, 15000, 15000, DIRECT);
     for (int j = 0; j < 8; ++j) x_out[(size_t)i * 8 + j] = x[j];
     f_out[i] = f;
     nit[i] = it;
@@ -47,7 +50,9 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 // Measured per pipelined step (bs=32, profiles/r02_decode3d_load.json): 8 objects per workgroup (178 VGPRs, no
 // scratch) 15.62 ms at 473 objects / 18.03 ms at 3200; 12 (168-VGPR cap) 16.02 / 18.40; 16 (128-VGPR cap,
 // 132 B of spills per lane) 16.12 / 18.49: the spills cost more than the denser packing saves.
+#ifndef D3_WPB_DEFAULT
 #define D3_WPB_DEFAULT 8
+#endif
 template <int D3_WPB>
 __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
@@ -124,16 +129,35 @@ extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t
     return 0;
 }
 
-// Same problem on the one-lane-per-object kernel (scalar lbfgsb.h): cross-check of the wave kernel.
+// Same problem on the one-lane-per-object kernels (scalar lbfgsb.h): cross-checks of the wave kernel.
+static int launch_scalar(int direct, void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                         const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit,
+                         int32_t* d_status, const char* what) {
+    if (N <= 0 || ncls <= 0) { rt_set_error("%s: bad sizes", what); return 1; }
+    if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) { rt_set_error("%s: null pointer", what); return 1; }
+    if (direct)
+        hipLaunchKernelGGL(decode3d_kernel<1>, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+                           d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    else
+        hipLaunchKernelGGL(decode3d_kernel<0>, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
+                           d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("%s launch: %s", what, hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// the product's arithmetic (direct two-loop direction), one lane per object: bit-identical to rtm3d_decode3d
 extern "C" int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                                      const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                                      double* d_fun, int32_t* d_nit, int32_t* d_status) {
-    if (N <= 0 || ncls <= 0) { rt_set_error("decode3d_scalar: bad sizes"); return 1; }
-    hipLaunchKernelGGL(decode3d_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, N, d_cls, d_verts,
-                       d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { rt_set_error("decode3d_scalar launch: %s", hipGetErrorString(e)); return 1; }
-    return 0;
+    return launch_scalar(1, stream, N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, "decode3d_scalar");
+}
+
+// the published subspace step (formk / subsm / formt), i.e. L-BFGS-B 3.0 as SciPy runs it, one lane per object
+extern "C" int rtm3d_decode3d_reference_form(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
+                                             const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
+                                             double* d_fun, int32_t* d_nit, int32_t* d_status) {
+    return launch_scalar(0, stream, N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, "decode3d_reference_form");
 }
 
 // ------------------------------------------------------------------------------------------------------------

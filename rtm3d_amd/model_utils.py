@@ -88,8 +88,10 @@ def decode_smoke_slots(det, reg_logits, K_per_image, dim_ref, down_sample=4.0, o
     return out
 
 
-def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_kernel=False):
-    """Raw solver results for N objects: (x (N,8), fun (N,), nit (N,), status (N,)) as numpy."""
+def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_kernel=False, reference_form=False):
+    """Raw solver results for N objects: (x (N,8), fun (N,), nit (N,), status (N,)) as numpy.
+    scalar_kernel / reference_form select the cross-check kernels (include/rtm3d_hip.h): one lane per object with the
+    product's arithmetic, or with L-BFGS-B's published subspace step (the form SciPy runs)."""
     lib = _lib.load()
     dev = _device(device)
     clses = np.asarray(clses).reshape(-1)
@@ -108,7 +110,7 @@ def solve_boxes(clses, bbox3d_projs, K, ref_dim, ref_loc, device=None, scalar_ke
         d_dim = torch.as_tensor(np.asarray(ref_dim, np.float64), device=dev).contiguous()
         d_loc = torch.as_tensor(np.asarray(ref_loc, np.float64), device=dev).contiguous()
         out = Boxes3D(N, dev)
-        fn = lib.rtm3d_decode3d_scalar if scalar_kernel else lib.rtm3d_decode3d
+        fn = lib.rtm3d_decode3d_reference_form if reference_form else (lib.rtm3d_decode3d_scalar if scalar_kernel else lib.rtm3d_decode3d)
         _lib.check(fn(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), N, d_cls.data_ptr(),
                                       d_uv.data_ptr(), d_K.data_ptr(), d_dim.data_ptr(), int(d_dim.shape[0]), d_loc.data_ptr(),
                                       out.x.data_ptr(), out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode3d')

@@ -127,6 +127,26 @@ def test_decode3d_wave_kernel_equals_scalar_kernel(dev):
         np.testing.assert_array_equal(u, v)
 
 
+def test_decode3d_product_form_vs_published_form(dev):
+    """The product computes the search direction by the two-loop recursion; rtm3d_decode3d_reference_form runs L-BFGS-B's
+    published subspace step (formk / subsm / formt, the form SciPy runs) on the same objects: identical keep / reject
+    decisions, kept boxes within 1e-6 (bar 1e-4); objects the reference rejects are not compared in x (their path is chaotic
+    in either form) but end at the same objective value."""
+    g = load_golden('decode3d_cases.npz')
+    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
+    b = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], reference_form=True)
+    kept = b[1] < 0.1
+    np.testing.assert_array_equal(a[1] < 0.1, kept)
+    np.testing.assert_array_equal(kept, g['raw_fun'] < 0.1)
+    np.testing.assert_allclose(a[0][kept], b[0][kept], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=1e-8)
+    record_measurement('decode3d_product_vs_published_form', 'decode3d_cases',
+                       {'kept_x_linf': float(np.abs(a[0] - b[0])[kept].max()), 'all_x_linf': float(np.abs(a[0] - b[0]).max()),
+                        'nit_mean_product': float(a[2].mean()), 'nit_mean_published': float(b[2].mean())})
+    # the published form on the device reproduces the host build of the same header bit for bit (no contraction, same order)
+    np.testing.assert_allclose(b[0][kept], g['raw_x'][kept], rtol=0, atol=1e-7)
+
+
 def test_decode3d_random_vs_scipy(dev):
     """Fresh objects: same answer as the SciPy-driven oracle within 1e-4 (kept objects)."""
     rng = np.random.Generator(np.random.PCG64(2024))

@@ -11,9 +11,7 @@ from rtm3d_amd import _lib, model_utils  # noqa: E402
 
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])      # the diagnostic build, not the in-tree library
 view = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-NAMES = {1: ['formk', 'subsm', 'line search', 'matupd', 'formt', '-', '-', 'total'],
-         2: ['formk.shift', 'formk.dots', 'formk.fill', 'formk.potrf1', 'formk.rhs', 'formk.upd22', 'formk.potrf2', '-'],
-         3: ['subsm.trsv_ut', 'subsm.trsv_un', '-', '-', '-', '-', '-', '-']}[view]
+NAMES = {1: ['direction (two-loop)', '-', 'line search', 'matupd', '-', '-', '-', 'total']}[view]
 g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'decode3d_cases.npz'))
 x, fun, nit, st = model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
 ok = st == 0

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Diagnostic: builds three -DLBW_PROF=k copies of the library (the in-tree one stays untouched) and runs tools/prof_lbw.py
-# on each.  Build HERE (no GPU needed):  bash tools/prof_lbw.sh build ; then  gpurun -- 'bash tools/prof_lbw.sh run'
+# Diagnostic: builds a -DLBW_PROF=1 copy of the library (the in-tree one stays untouched) and runs tools/prof_lbw.py
+# on it.  Build HERE (no GPU needed):  bash tools/prof_lbw.sh build ; then  gpurun -- 'bash tools/prof_lbw.sh run'
 set -e
 cd $(dirname $0)/..
-for k in 1 2 3; do
+for k in 1; do
   D=$PWD/rtm3d_amd/_C/prof$k
   if [ "$1" = build ]; then
     mkdir -p $D/obj
