@@ -22,7 +22,7 @@ import numpy as np
 from . import _lib
 from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS, head_table
 
-V2_MIN_TILES = 512
+V2_MIN_TILES = 200
 FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 stride-2 conv in one launch (conv32s2_fused.hip)
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
@@ -392,7 +392,10 @@ def choose_bn_tile(cout, M):
     return 64
 
 
-def choose_variant(cin, cout, M, groups, out_nchw):
+V2_MIN_TILES_SHALLOW = 512   # layers with a short K loop (1x1 convs) or stride 2: two full rounds, as before
+
+
+def choose_variant(cin, cout, M, groups, out_nchw, ntaps=9, stride=1):
     """2 = 256x256-tile 8-wave kernel (conv_mfma256.hip) when the layer has enough tiles to fill the
     chip at one workgroup per CU; 0 = 128-pixel-tile kernel (conv_mfma.hip); 3 = register-direct MFMA kernel for the
     4/16/32-channel layers of the stems (conv_smallc.hip)."""
@@ -401,12 +404,16 @@ def choose_variant(cin, cout, M, groups, out_nchw):
             raise NotImplementedError('no HIP kernel for a convolution with %d input channels (supported: 4, 16, 32, multiples of 64)' % cin)
         return 3
     if not out_nchw and cout % 256 == 0:
-        # one persistent workgroup per CU (256 CUs): at least two full rounds.  (A single nearly full round -
-        # DLA level4, 240 tiles - is 0.1 ms faster per forward on its own but 0.4 ms slower per pipelined
-        # step, measured twice (one-tile and persistent kernel): early in the forward the 3D decode of the
-        # previous batch still holds ~60 CUs, whose waves cannot share a SIMD with this kernel, and with one
-        # tile per CU there is nothing for the ticket scheduler to rebalance.)
-        if ((M + 255) // 256) * (cout // 256) * groups >= V2_MIN_TILES:
+        # one persistent workgroup per CU (256 CUs): at least ~a round of tiles.  History: up to the end of round 2 the bar was two
+        # full rounds (512): a single nearly full round - DLA level4, 240 tiles - was 12 % faster per launch on this kernel but
+        # 0.1-0.5 ms SLOWER per pipelined step, because the previous batch's 3D decode (178 VGPRs x 8 waves and 67 KB of LDS per
+        # workgroup, resident for ~3 ms) held ~60 CUs that a 160 KB workgroup cannot share.  With the direct-form solver
+        # (116 VGPRs, 20 KB, ~1 ms beside the forward) the same switch gains 0.08-0.13 ms per step (tools/gpu_v2tiles_ab.sh:
+        # 14.03 / 14.09 / 14.08 -> 13.95 / 13.96 / 14.01 ms).
+        # (the 1x1 projections / roots and the stride-2 entry conv of level4 measured 0.023 / 0.052 ms on this kernel against
+        # 0.019 / 0.049 on the 128-pixel one: the single-round bar is for stride-1 layers with at least 8 K-steps)
+        deep = stride == 1 and ntaps * cin // 64 >= 8
+        if ((M + 255) // 256) * (cout // 256) * groups >= (V2_MIN_TILES if deep else max(V2_MIN_TILES, V2_MIN_TILES_SHALLOW)):
             return 2
     return 0
 
@@ -668,7 +675,7 @@ class RealizedPlan(object):
                 M = P.B * op['Hm'] * op['Wm']
                 variant = op.get('variant')
                 if variant is None:
-                    variant = choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'])
+                    variant = choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'], len(op['taps'][0]), op['in_stride'])
                 ok = ok and variant == 2 and op['cout'] == 256 and G <= 4 and op['in_stride'] == 1 and not op['out_nchw']
                 ok = ok and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0 and len(op['taps'][0]) in (4, 9)
                 ok = ok and all(r is None for r in op['res']) and all(o.coff == 0 and o.C == 256 for o in op['out'])
@@ -715,7 +722,7 @@ class RealizedPlan(object):
         variant = op.get('variant')
         if variant is None:
             variant = (5 if conv64_eligible(op) else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)
-                       else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw']))
+                       else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'], len(op['taps'][0]), op['in_stride']))
         if variant == 6:
             d.kernel, d.bn_tile = 6, 128
             d.w_blob = self._blob(self._packed(op, 0, 'mfma', 128, lambda: pack_mfma_weights(op['w'][0], 128)[0]))
