@@ -43,13 +43,14 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
     status[i] = st;
 }
 
-// One wavefront per object (lbfgsb_wave.h): the production kernel.  A workgroup packs D3_WPB objects
-// (8 waves, 67 KB of LDS): the ~15 objects of an image then sit on two CUs instead of fifteen, which
-// matters when this kernel runs beside the forward pass of the next batch - a CU that holds even one
-// of these waves cannot take a workgroup of the persistent conv kernel until the wave retires.
-// Measured per pipelined step (bs=32, profiles/r02_decode3d_load.json): 8 objects per workgroup (178 VGPRs, no
-// scratch) 15.62 ms at 473 objects / 18.03 ms at 3200; 12 (168-VGPR cap) 16.02 / 18.40; 16 (128-VGPR cap,
-// 132 B of spills per lane) 16.12 / 18.49: the spills cost more than the denser packing saves.
+// One wavefront per object (lbfgsb_wave.h): the production kernel.  A workgroup packs D3_WPB objects (8 waves, 20 KB of
+// LDS, 116 VGPRs): the ~15 objects of an image then sit on two CUs instead of fifteen, which matters when this kernel runs
+// beside the forward pass of the next batch - a CU that holds these waves cannot take a workgroup of the persistent conv
+// kernels (160 KB of LDS) until they retire.  Objects per workgroup, pipelined ms/step at bs=1 serial / bs=32 with 473 /
+// with 3200 objects, pairs measured on one box each (profiles/r02_decode3d_load.json): 8 vs 16: 1.57 / 14.04 / 14.97 vs
+// 1.65 / 14.18 / 15.16; 8 vs 4: 1.57 / 14.06 / 15.01 vs 1.52 / 14.05 / 15.01; 8 vs 2: 1.57 / 14.01 / 15.01 vs 1.53 / 14.04 / 15.06:
+// flat between 2 and 8, 8 kept.  (With the published subspace step - 178 VGPRs, 67 KB per 8 objects - 12 and 16 objects per
+// workgroup needed VGPR caps that spilled: 15.62 / 16.02 / 16.12 ms per step at 473 objects.)
 #ifndef D3_WPB_DEFAULT
 #define D3_WPB_DEFAULT 8
 #endif
