@@ -771,7 +771,7 @@ def test_fp32_verify_logits_vs_reference_golden(dev, fname):
         vmax = max(vmax, float(np.abs(to_np(d[3][b]) - rv).max()))
         checked += int(n[b])
     record_measurement('fp32_verify_detections_vs_reference_golden', fname, {'matched': checked, 'score_linf': smax, 'vertex_linf_px': vmax})
-    assert checked >= 12 * B and vmax < FP32_VERT_TOL_PX and smax < 1e-5, (checked, vmax, smax)
+    assert checked >= 12 * B and vmax < FP32_VERT_TOL_PX and smax < 1.5e-5, (checked, vmax, smax)      # scores: 2 x the measured 7.1e-6
 
 
 def test_fp32_verify_end_to_end_boxes_vs_reference(dev):
