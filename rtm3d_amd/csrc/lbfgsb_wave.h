@@ -215,7 +215,9 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
                 gdold = gd;
                 if (gd >= 0.0) { info = -4; break; }
             }
+            PTB(tc_);
             const int task = lb_dcsrch(f, gd, &stp, ftol, gtol, xtol, 0.0, stpmx, start, &S);
+            PTE(tc_, 5);
             start = 0;
             if (task == LS_ERROR) { info = -4; break; }
             if (task == LS_CONV || task == LS_WARN) break;
@@ -224,7 +226,9 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (lane < n) w->x[lane] = (stp == 1.0) ? w->z[lane] : stp * w->d[lane] + w->t[lane];
             WSYNC();
             if (iback >= maxls) { ls_fail = 1; break; }
+            PTB(tf_);
             f = lbw_fg(w, K, lane);
+            PTE(tf_, 4);
         }
         PTE(tl_, 2);
         if (info != 0 || ls_fail) {

@@ -11,7 +11,7 @@ from rtm3d_amd import _lib, model_utils  # noqa: E402
 
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])      # the diagnostic build, not the in-tree library
 view = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-NAMES = {1: ['direction (two-loop)', '-', 'line search', 'matupd', '-', '-', '-', 'total']}[view]
+NAMES = {1: ['direction (two-loop)', '-', 'line search', 'matupd', 'ls: f + g', 'ls: dcsrch', '-', 'total']}[view]
 g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'decode3d_cases.npz'))
 x, fun, nit, st = model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
 ok = st == 0
