@@ -526,6 +526,30 @@ def test_two_stream_pipeline_equals_serial_path(dev, B):
     assert len(recs) == B and all(r is None or r['verts'].shape[1:] == (8, 2) for r in recs)
 
 
+def test_two_stream_pipeline_with_saturated_topk(dev):
+    """Maximum load of the decode: a dense heat map fills all 100 slots of every image (the regime of a trained checkpoint on
+    a crowded scene, bench.py --heat-bias 2): 400 objects per batch through decode2d -> decode3d_slots -> pack, pipelined
+    records equal to the serial path, every slot solved."""
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    bb = 'RESNET-18'
+    m = make_model(bb, weights.synth_state_dict(bb, 1, 'trained', heat_bias=2.0))
+    B = 4
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), device=dev)
+    xs = [weights.synth_images(B, 64, 128, seed=300 + i).to(dev) for i in range(3)]
+    pipe = Detect3DPipeline(m, B, dev, gather=False)
+    got = []
+    for x in xs:
+        got.append(pipe.results(pipe.submit(x, K)).clone())
+    pipe.drain()
+    for x, g_ in zip(xs, got):
+        det, boxes, _ = m.detect3d(x, K)
+        ref = pack_records_reference(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, 100, boxes)
+        torch.cuda.synchronize()
+        assert det.n.cpu().tolist() == [100] * B
+        assert (boxes.status.cpu().numpy() >= 0).all()
+        assert torch.equal(g_, ref)
+
+
 def test_pack_records_hip_equals_reference(dev):
     """rtm3d_pack_records (one HIP launch) against the plain-torch definition of the record: every field incl. the fp64
     atan2, the kept flag at the fun < 0.1 edge and the zeroing of empty slots."""
