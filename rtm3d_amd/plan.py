@@ -477,7 +477,7 @@ def conv64_eligible(op):
 
 
 USE_CONV128 = True
-C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small-launch kernels of conv_mfma.hip do better
+C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small-launch kernels of conv_mfma.hip do better (ResNet-18 bs=8, 240 tiles: 3.87 ms per step on this kernel against 3.76)
 
 
 def conv128_eligible(op, B):
