@@ -3,7 +3,8 @@ vectors of the real reference and against the CPU oracle on fresh seeded inputs.
 
 Bars: decode indices / classes bit-exact; decode float outputs bit-exact (same fp32 operation order
 and the ATen sigmoid reproduced); 3D boxes within 1e-4 (north_star); network logits (fp16 storage,
-fp32 accumulation) within 0.03 x logit scale of the fp32 reference, with the stated tolerance."""
+fp32 accumulation) within 2 x the measured error of the fp32 reference (LOGIT_RTOL below); in the fp32
+verification mode within 2e-5 of scale, identical detections."""
 import ctypes
 
 import numpy as np
