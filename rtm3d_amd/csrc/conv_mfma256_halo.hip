@@ -349,6 +349,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                         for (int d = 0; d < 2; ++d) { ROW_ROR_MAX(8) ROW_ROR_MAX(4) ROW_ROR_MAX(2) ROW_ROR_MAX(1) }
                         __builtin_memcpy(&mx, mu, 8);
                         const f32x4 M = {(float)mx[0], (float)mx[1], (float)mx[2], (float)mx[3]};
+                        // exp(h - M) = exp2(h * log2(e) - M * log2(e)): one mixed-precision fma (fp16 source, fp32 result: no separate
+                        // conversion) + v_exp_f32 + the add per element instead of cvt, sub, mul, exp, add
+                        const float L2E = 1.4426950408889634f;
+                        const f32x4 nMl = {-M[0] * L2E, -M[1] * L2E, -M[2] * L2E, -M[3] * L2E};
                         float S[4] = {0.f, 0.f, 0.f, 0.f};     // (scalars: update_dpp on ext-vector elements was miscompiled)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                             for (int p = 0; p < 4; ++p) {
                                 const f16x4 h = hq[i][p][j][cc];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) S[e] += __expf((float)h[e] - M[e]);
+                                for (int e = 0; e < 4; ++e) S[e] += __builtin_amdgcn_exp2f(__builtin_fmaf((float)h[e], L2E, nMl[e]));
                             }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { ROW_ROR_ADD(8) ROW_ROR_ADD(4) ROW_ROR_ADD(2) ROW_ROR_ADD(1) }
