@@ -16,8 +16,9 @@
  *   - every function returns 0 on success, non-zero on error; rtm3d_last_error() then returns a
  *     thread-local description.  "No detections" is not an error (n_out[b] == 0), mirroring the
  *     `None` list entries of models/model.py:33-44;
- *   - a context is not re-entrant: one caller thread / one stream at a time, one context per
- *     process-GPU (the reference is single-threaded per process, train_multi_gpu.py:243).
+ *   - a context is not re-entrant: one caller thread at a time, one context per process-GPU (the reference is
+ *     single-threaded per process, train_multi_gpu.py:243).  Replays of one context never overlap on the device: calls on
+ *     one stream are ordered by the stream, a call on a different stream is ordered behind the previous replay by an event.
  */
 #ifndef RTM3D_HIP_H
 #define RTM3D_HIP_H

@@ -68,6 +68,11 @@ struct rtm3d_ctx {
     // hipGraph replay (rtm3d_ctx_set_graph): one instantiated graph per distinct (input, 4 x output) pointer tuple
     int graph_mode = 0;
     hipStream_t capture_stream = nullptr;
+    // a context owns ONE activation workspace and one set of ticket counters: replays must not overlap.  Calls on the same
+    // stream are ordered by the stream; a call on a different stream first waits for the previous replay (done_ev)
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t done_ev = nullptr;
     struct GraphEntry { const void* key[5]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0;
@@ -115,6 +120,7 @@ extern "C" void rtm3d_ctx_destroy(rtm3d_ctx* ctx) {
     for (auto e : ctx->probe_ev) (void)hipEventDestroy(e);
     for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
     if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
+    if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
     delete ctx;
 }
 
@@ -614,11 +620,23 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
 
 static const size_t GRAPH_CACHE = 8;
 
+static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4]);
+
 extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
     if (!ctx || !d_out_logits) RT_FAIL("forward: null argument");
     if (!d_out_logits[0]) RT_FAIL("forward: null logits buffer 0");
     if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
     hipStream_t s = (hipStream_t)stream;
+    // the previous replay ran on another stream: order this one behind it (the workspace and the ticket counters are shared)
+    if (ctx->has_last && ctx->last_stream != s) RT_HIP(hipStreamWaitEvent(s, ctx->done_ev, 0));
+    if (forward_on_stream(ctx, s, d_in, d_out_logits)) return 1;
+    if (!ctx->done_ev) RT_HIP(hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
+    RT_HIP(hipEventRecord(ctx->done_ev, s));
+    ctx->last_stream = s; ctx->has_last = true;
+    return 0;
+}
+
+static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4]) {
     if (!ctx->graph_mode || ctx->probe_op >= 0) return replay_eager(ctx, s, d_in, d_out_logits, true);
     // graph replay: the kernel arguments are baked into the graph, so it is keyed by the caller's buffers (a serving
     // loop re-uses the same few buffers: torch's caching allocator hands back the same blocks)

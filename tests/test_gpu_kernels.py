@@ -409,3 +409,30 @@ def test_fused_level_entry_vs_torch(shape):
     for fuse in (True, False):
         np.testing.assert_allclose(res[fuse][0], ref_r, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref_r).max()))
         np.testing.assert_allclose(res[fuse][1], ref_m, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref_m).max()))
+
+
+def test_forward_on_two_streams_is_serialised():
+    """one context = one activation workspace and one set of ticket counters.  Two replays issued back to back on
+    DIFFERENT streams must not overlap on the device: rtm3d_forward orders a call on a new stream behind the previous replay."""
+    import rtm3d_amd
+    from rtm3d_amd import weights
+    bb = 'RESNET-18'
+    m = rtm3d_amd.create_model(rtm3d_amd.kitti_config(bb)).to('cuda:0').eval()
+    m.load_state_dict(weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0))
+    m.use_graph = False
+    xa = weights.synth_images(4, 128, 256, seed=1).cuda()
+    xb = weights.synth_images(4, 128, 256, seed=2).cuda()
+    ra = [t.clone() for t in m.forward_logits(xa)]
+    rb = [t.clone() for t in m.forward_logits(xb)]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(sa):
+            ga = m.forward_logits(xa)
+        with torch.cuda.stream(sb):
+            gb = m.forward_logits(xb)
+        torch.cuda.synchronize()
+        for a, b in zip(ga, ra):
+            assert torch.equal(a, b)
+        for a, b in zip(gb, rb):
+            assert torch.equal(a, b)
