@@ -48,7 +48,7 @@ def test_lbfgsb_header_host_build_matches_scipy(built, form):
 
 
 def test_lbfgsb_direct_form_on_reference_kept_objects(built):
-    """The product form on every e2e / planted fixture (232 further objects the reference solved): identical keep / reject
+    """The product form on every e2e / planted fixture (286 further objects the reference solved): identical keep / reject
     decisions, kept boxes within 1e-6 of the reference's (bar 1e-4), objective values within 1e-2 relative."""
     from tests.golden.cases import DIM_REF
     lib = ctypes.CDLL(os.path.join(REPO, 'tests', '_build', 'libhost_lbfgsb.so'))
