@@ -64,6 +64,8 @@ def parse_args():
                          'preprocessed once, outside the timed region, into the fp32 NCHW batch that is then fed like the BASELINE line (the A/B partner)')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
+    ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
+    ap.add_argument('--dry-launch', action='store_true', help='launcher rehearsal over gloo on CPU tensors, no GPU and no hot path (line marked INVALID)')
     return ap.parse_args()
 
 
@@ -304,23 +306,119 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start the N ranks of `--gpus N` as FRESH child processes under torch.distributed.run (what the reference does with
+    mp.spawn, /root/reference/train_multi_gpu.py:239-245) and return their exit code.  Called before anything in this
+    process has touched the GPU; the current process is never replaced (no exec): it waits and exits with the children's rc."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    env['RTM3D_BENCH_LAUNCHED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print('bench.py: starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def multi_diagnostics(world, B, steps, dt, rec, local, dev, gather_us):
+    """Diagnostics of an N-rank run, outside the timed region: max-over-ranks wall time, every rank's own ms/step, and how
+    many ranks' record blocks arrived intact in this rank's gathered batch (checksum of each rank's local block, gathered
+    separately, against the block sums of the gathered records)."""
+    mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+    allt = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allt, mine)
+    t = mine.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    multi = {'per_rank_ms_per_step': [round(v / steps * 1e3, 3) for v in allt.tolist()]}
+    cs = local.double().sum().reshape(1)
+    allcs = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allcs, cs)
+    ok = rec.shape[0] == world * B
+    blocks = rec.reshape(world, -1).double().sum(1) if ok else None
+    multi['ranks_seen'] = int((blocks == allcs).sum().item()) if ok else 0
+    multi['gathered_shape'] = list(rec.shape)
+    multi['allgather_us_last_step'] = round(gather_us, 1) if gather_us is not None else None
+    multi['allgather_bytes_per_rank'] = int(local.numel() * 4)
+    return float(t.item()), multi
+
+
+def dry_launch(args, world, rank):
+    """`--dry-launch`: the launcher, the rank/shard plumbing, the preallocated all-gather of (B, topk, 32) records and the
+    JSON line rehearsed over gloo on CPU tensors - NO GPU is touched and nothing of the hot path runs, so the line is
+    marked INVALID and carries no throughput.  Exists so that `bench.py --gpus N` can be tested where there is no N-GPU box."""
+    from rtm3d_amd import distributed as rdist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    B, topk = args.batch, 100
+    dev = torch.device('cpu')
+    lo, hi, per = rdist.padded_shard(B * world, rank, world)
+    assert (lo, hi, per) == (rank * B, rank * B + B, B)
+    g = torch.Generator().manual_seed(99 + rank)
+    local = torch.rand(B, topk, rdist.RECORD, generator=g)
+    local[:, :, 0] = rank                                   # every block names its rank
+    out = rdist.gathered_buffer(local)
+
+    def fence():
+        dist.barrier()
+    for _ in range(args.warmup):
+        rdist.all_gather_records(local, always=True, out=out)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = rdist.all_gather_records(local, always=True, out=out)
+    fence()
+    dt = time.perf_counter() - t0
+    dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, None)
+    multi['block_ranks'] = [int(v) for v in rec.reshape(world, B, topk, rdist.RECORD)[:, 0, 0, 0].tolist()]
+    if rank == 0:
+        print(json.dumps({'metric': 'images_per_sec', 'value': None, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'fp16', 'data': 'synthetic',
+                          'config': {'workload': 'DRY LAUNCH: launcher + gloo all-gather of (%d, %d, 32) records only' % (B, topk),
+                                     'global_batch': B * world, 'parallelism': 'dp%d' % world},
+                          'INVALID': 'dry launch (gloo, CPU tensors, no hot path): launcher rehearsal only',
+                          'multi_gpu': multi}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    launched = 'RANK' in os.environ
+    if not launched and (args.gpus > 1 or args.force_launch):
+        # BEFORE any GPU call: N fresh rank processes, this one only waits for them.  device_count() does not initialise HIP
+        if not args.dry_launch:
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit('bench.py: --gpus %d but this node shows %d GPUs' % (args.gpus, have))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        # a launcher that started a different number of ranks than the line would claim: refuse, never measure N silently
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    # under torchrun (RANK set) the process group is created even for one rank, so that the collective path of the
+    # under a launcher (RANK set) the process group is created even for one rank, so that the collective path of the
     # N > 1 runs (RCCL all-gather on the side stream + the diagnostics below) can be rehearsed on a one-GPU box
-    use_dist = world > 1 or 'RANK' in os.environ
+    use_dist = world > 1 or launched
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=dev)
-    if args.gpus != world and rank == 0:
-        print('note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
     import rtm3d_amd
     from rtm3d_amd import weights, distributed as rdist
@@ -410,16 +508,6 @@ def main():
     dt = time.perf_counter() - t0
     last_step = rec
     multi = None
-    if use_dist:
-        # diagnostics for the scaling run (outside the timed region): every rank's own wall time, the device time of the
-        # last all-gather, and how many ranks' record blocks arrived intact in rank 0's gathered batch
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
-        allt = torch.empty(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allt, mine)
-        t = mine.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        multi = {'per_rank_ms_per_step': [round(v / args.steps * 1e3, 3) for v in allt.tolist()]}
     dom_ms, dom_n = plan.probe_read() if not args.graph else (info[dom]['ms'], 0)
     n_det = det.n.sum().item()
     if pipe is not None:
@@ -427,14 +515,7 @@ def main():
     if use_dist:
         torch.cuda.synchronize(dev)
         local = pipe.rec_local[last_step % pipe.depth] if pipe is not None else rec[rank * B:(rank + 1) * B]
-        cs = local.double().sum().reshape(1)
-        allcs = torch.empty(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allcs, cs)
-        blocks = rec.view(world, -1).double().sum(1)
-        multi['ranks_seen'] = int((blocks == allcs).sum().item()) if rec.shape[0] == world * B else 0
-        multi['gathered_shape'] = list(rec.shape)
-        multi['allgather_us_last_step'] = round(pipe.gather_us(last_step), 1) if pipe is not None else None
-        multi['allgather_bytes_per_rank'] = int(local.numel() * 4)
+        dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, pipe.gather_us(last_step) if pipe is not None else None)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

@@ -59,8 +59,16 @@ def trim_gathered(rec, total):
     return rec[:total]
 
 
-def all_gather_records(rec, group=None, check_shapes=False, always=False):
-    """(b, topk, 32) per rank -> (world*b, topk, 32) ordered by global image index.  One collective."""
+def gathered_buffer(rec_like, group=None):
+    """A (world*b, topk, 32) buffer for ``all_gather_records(out=...)``: allocate it once per pipeline slot so that the
+    per-step path neither allocates on the side stream nor hands a side-stream block to another stream's consumers."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    return torch.zeros((world * rec_like.shape[0],) + tuple(rec_like.shape[1:]), dtype=rec_like.dtype, device=rec_like.device)
+
+
+def all_gather_records(rec, group=None, check_shapes=False, always=False, out=None):
+    """(b, topk, 32) per rank -> (world*b, topk, 32) ordered by global image index.  One collective.
+    ``out``: preallocated result (``gathered_buffer``); without it a fresh tensor is allocated on the current stream."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return rec
     world = dist.get_world_size(group)
@@ -75,7 +83,12 @@ def all_gather_records(rec, group=None, check_shapes=False, always=False):
         if not torch.equal(lo, hi):
             raise ValueError('all_gather_records: shard shapes differ across ranks (%s..%s); pad with padded_shard()'
                              % (lo.tolist(), hi.tolist()))
-    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    shape = (world * rec.shape[0],) + tuple(rec.shape[1:])
+    if out is None:
+        out = torch.empty(shape, dtype=rec.dtype, device=rec.device)
+    elif tuple(out.shape) != shape or out.dtype != rec.dtype or out.device != rec.device or not out.is_contiguous():
+        raise ValueError('all_gather_records: out must be a contiguous %s %s tensor on %s, got %s %s on %s'
+                         % (shape, rec.dtype, rec.device, tuple(out.shape), out.dtype, out.device))
     dist.all_gather_into_tensor(out, rec, group=group)
     return out
 

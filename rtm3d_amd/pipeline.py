@@ -56,6 +56,13 @@ class Detect3DPipeline(object):
             self.ev_a = [torch.cuda.Event() for _ in range(depth)]
             self.ev_b = [torch.cuda.Event() for _ in range(depth)]
             self.rec_local = [torch.zeros(batch, self.topk, rdist.RECORD, dtype=torch.float32, device=self.dev) for _ in range(depth)]
+            # per-slot copies of everything the side stream reads or writes, allocated ONCE on the construction stream: the
+            # gathered records (no allocation on the side stream per step, no side-stream block handed to main-stream
+            # consumers) and the intrinsics (the caller may drop or overwrite its K tensor right after submit())
+            gathers = bool(gather) and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                (gather == 'always' or torch.distributed.get_world_size() > 1)
+            self.rec_all = [rdist.gathered_buffer(self.rec_local[0]) for _ in range(depth)] if gathers else None
+            self.K_slot = [torch.zeros(batch, 9, dtype=torch.float64, device=self.dev) for _ in range(depth)]
             # optional event pair around the collective (bench diagnostics; timing events are not free, so off by default)
             self.time_gather = False
             self.ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
@@ -117,6 +124,8 @@ class Detect3DPipeline(object):
             main.wait_event(self.ev_b[s])                 # slot s is free again
         logits = run_network()
         self.model.decode2d(logits, out=self.det[s])
+        self.K_slot[s].copy_(K_per_image.reshape(self.B, 9), non_blocking=True)     # main stream, ordered before A_s
+        K_per_image = self.K_slot[s]
         self.ev_a[s].record(main)
         side = self.sides[s % len(self.sides)]
         with torch.cuda.stream(side):
@@ -128,7 +137,8 @@ class Detect3DPipeline(object):
                                      self.boxes[s] if self.decode3d else None, out=self.rec_local[s])
             if self.time_gather:
                 self.ev_g0[s].record(side)
-            self.rec[s] = rdist.all_gather_records(rec, always=self.gather == 'always') if self.gather else rec
+            self.rec[s] = rdist.all_gather_records(rec, always=self.gather == 'always',
+                                                   out=self.rec_all[s] if self.rec_all is not None else None) if self.gather else rec
             if self.time_gather:
                 self.ev_g1[s].record(side)
             self.ev_b[s].record(side)

@@ -365,3 +365,57 @@ def test_float_estimate_division_is_exact_for_small_quotients():
         r = m - q * d
         q = q + (r >= d).astype(np.int64) - (r < 0).astype(np.int64)
         np.testing.assert_array_equal(q, m // d)
+
+
+# ------------------------------------------------------------------ bench.py rank launcher
+def _run_bench(argv, env_extra=None, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('n', [2, 8])
+def test_bench_launcher_dry_launch(n):
+    """`python bench.py --gpus N` must start N ranks ITSELF (the reference: mp.spawn, train_multi_gpu.py:239-245).  Rehearsed
+    without GPUs: --dry-launch runs the launcher, the shard plumbing and the preallocated all-gather over gloo and prints the
+    JSON line with n_gpus = N and every rank's record block seen intact; the line is marked INVALID (no hot path ran)."""
+    import json
+    r = _run_bench(['--gpus', str(n), '--dry-launch', '--steps', '2', '--warmup', '1', '--batch', '32' if n == 8 else '4'])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                       # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == n and out['multi_gpu']['ranks_seen'] == n
+    assert out['multi_gpu']['block_ranks'] == list(range(n))           # ordered by global image index
+    assert len(out['multi_gpu']['per_rank_ms_per_step']) == n
+    assert out['config']['global_batch'] == n * (32 if n == 8 else 4)
+    assert 'INVALID' in out and out['value'] is None
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Under a launcher that started a different number of ranks than --gpus claims, bench.py exits non-zero (it used to
+    print a note and measure WORLD_SIZE ranks silently)."""
+    r = _run_bench(['--gpus', '4', '--dry-launch'], {'RANK': '0', 'WORLD_SIZE': '2', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(['--gpus', '2'])                      # fewer GPUs than ranks: the launcher refuses before starting anything
+        assert r.returncode != 0 and 'GPUs' in r.stderr
+
+
+def test_all_gather_records_out_buffer_checks():
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(29700 + os.getpid() % 200)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        rec = torch.rand(3, 100, rdist.RECORD)
+        buf = rdist.gathered_buffer(rec)
+        out = rdist.all_gather_records(rec, always=True, out=buf)
+        assert out is buf and torch.equal(buf, rec)
+        with pytest.raises(ValueError):
+            rdist.all_gather_records(rec, always=True, out=torch.zeros(2, 100, rdist.RECORD))
+    finally:
+        dist.destroy_process_group()

@@ -615,6 +615,26 @@ def test_pipeline_under_nccl_world1(dev):
     assert 'nccl world-1 pipeline ok' in r.stdout
 
 
+def test_bench_spawn_path_nccl_world1(dev):
+    """`bench.py --gpus 1 --force-launch`: the launcher bench.py uses for --gpus N > 1 (fresh rank processes under
+    torch.distributed.run, started before the parent touches the GPU), at the one rank this box has: the rank creates the
+    RCCL process group, runs the pipelined steps with the preallocated all-gather and reports n_gpus / ranks_seen."""
+    import subprocess, sys, os, json
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-launch', '--steps', '3', '--warmup', '1',
+                        '--batch', '4', '--height', '128', '--width', '256', '--backbone', 'RESNET-18', '--no-cpu-baseline', '--no-parity'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['multi_gpu']['ranks_seen'] == 1 and out['multi_gpu']['gathered_shape'] == [4, 100, 32]
+    assert out['multi_gpu']['allgather_us_last_step'] > 0 and out['value'] > 0
+
+
 def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
     """hipGraph replay of the plan (small batches) against the eager replay: same logits bit for bit, over several
     replays, fresh input/output buffers (new graph keys) and a second shape; the plan cache keeps at most MAX_PLANS."""
