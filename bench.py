@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-full', action='store_true', help='whole BASELINE.md section-4 CPU protocol (adds minutes: one-thread bs=8)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the all-thread CPU legs (0: min(scheduler affinity, cgroup CPU quota))')
     ap.add_argument('--no-parity', action='store_true', help='skip the 3D-box L-inf check against the CPU oracle')
     ap.add_argument('--parity-images', type=int, default=2)
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
@@ -74,48 +75,101 @@ def _best_median(ts):
     return ts[0], ts[len(ts) // 2]
 
 
-def cpu_baseline(backbone, sd, H, W, cfg, full=False):
-    """The oracle timed on this host, BASELINE.md section 4: all host threads and one thread, bs=1 and bs=8,
+def host_cpu_info():
+    """What this process may really use: scheduler affinity, the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us), the CPU
+    model.  `usable` = min(affinity, ceil(quota)) is the thread count of the all-thread legs: more OpenMP threads than the
+    quota admits only time-slice against each other (r02: 128 threads inside a smaller quota ran 1.46x one thread)."""
+    import math
+    info = {'os_cpu_count': os.cpu_count()}
+    try:
+        info['affinity'] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info['affinity'] = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                      # cgroup v2: "max 100000" or "<quota> <period>"
+            q, per = f.read().split()[:2]
+            quota = None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:     # cgroup v1
+                q = float(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = float(f.read())
+            quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    info['cgroup_cpu_quota'] = quota
+    model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    info['cpu_model'] = model
+    info['usable'] = max(1, min(info['affinity'], int(math.ceil(quota)) if quota else info['affinity']))
+    return info
+
+
+def cpu_baseline(backbone, sd, H, W, cfg, full=False, threads=None):
+    """The oracle timed on this host, BASELINE.md section 4: all usable host threads and one thread, bs=1 and bs=8,
     1 warm-up + 3 timed runs (best / median), forward + 2D decode (images/s) and the SciPy 3D decode (objects/s)
     separately.  Bounded by default (about 30-40 s): the one-thread leg runs bs=1 once warm + 2 timed and skips bs=8
     unless --cpu-full.  `value` = whole path (forward + 2D + 3D decode of the detections found) at the best
-    all-thread configuration."""
+    all-thread configuration.  `cores` = the threads the all-thread legs really ran on (host_cpu_info()['usable'], or
+    --cpu-threads); every leg also reports process-CPU-seconds / wall-seconds (`cpus_busy`), so a leg that was not what its
+    name says (one thread that is not one, a pool throttled by a quota) shows in the line itself."""
     from oracle import rtm3d_ref, decode3d_ref
     from rtm3d_amd import weights
-    nthreads = torch.get_num_threads()
+    host = host_cpu_info()
+    torch_default = torch.get_num_threads()
+    nthreads = int(threads) if threads else host['usable']
+    torch.set_num_threads(nthreads)
     th, tk = cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES
     x8 = weights.synth_images(8, H, W, seed=1234)
     K = weights.synth_intrinsics()
     detail = {}
+    gflop_img = {'DLA-34': 436.28, 'RESNET-18': 411.62}.get(backbone)      # BASELINE.md section 3
 
     def time_forward(bs, runs, warm=1):
         for _ in range(warm):
             rtm3d_ref.model_forward(x8[:bs], sd, backbone, th, tk)
-        ts = []
+        ts, busy = [], []
         for _ in range(runs):
-            t0 = time.perf_counter()
+            c0, t0 = time.process_time(), time.perf_counter()
             dets, _ = rtm3d_ref.model_forward(x8[:bs], sd, backbone, th, tk)
-            ts.append(time.perf_counter() - t0)
-        return ts, dets
+            t1, c1 = time.perf_counter(), time.process_time()
+            ts.append(t1 - t0); busy.append((c1 - c0) / (t1 - t0))
+        return ts, dets, busy
+
+    def leg(bs, nt, ts, busy):
+        best, med = _best_median(ts)
+        d = {'best_s': best, 'median_s': med, 'images_per_s_best': bs / best, 'torch_threads': torch.get_num_threads(),
+             'cpus_busy': round(sorted(busy)[len(busy) // 2], 2)}
+        if gflop_img:
+            d['gflops_best'] = round(gflop_img * bs / best, 1)
+        detail['forward+decode2d bs=%d threads=%d' % (bs, nt)] = d
 
     dets8 = None
-    for bs in (1, 8):
-        ts, dets = time_forward(bs, 3)
-        best, med = _best_median(ts)
-        detail['forward+decode2d bs=%d threads=%d' % (bs, nthreads)] = {'best_s': best, 'median_s': med, 'images_per_s_best': bs / best}
-        if bs == 8:
-            dets8 = dets
-    torch.set_num_threads(1)
     try:
-        ts, _ = time_forward(1, 3 if full else 2)
-        best, med = _best_median(ts)
-        detail['forward+decode2d bs=1 threads=1'] = {'best_s': best, 'median_s': med, 'images_per_s_best': 1 / best}
+        for bs in (1, 8):
+            ts, dets, busy = time_forward(bs, 3)
+            assert torch.get_num_threads() == nthreads
+            leg(bs, nthreads, ts, busy)
+            if bs == 8:
+                dets8 = dets
+        torch.set_num_threads(1)
+        assert torch.get_num_threads() == 1
+        ts, _, busy = time_forward(1, 3 if full else 2)
+        leg(1, 1, ts, busy)
         if full:
-            ts, _ = time_forward(8, 3)
-            best, med = _best_median(ts)
-            detail['forward+decode2d bs=8 threads=1'] = {'best_s': best, 'median_s': med, 'images_per_s_best': 8 / best}
+            ts, _, busy = time_forward(8, 3)
+            leg(8, 1, ts, busy)
     finally:
-        torch.set_num_threads(nthreads)
+        torch.set_num_threads(torch_default)
     # 3D decode: SciPy L-BFGS-B with Python-level objective/gradient, one thread by construction
     objs = [(dets8[0][i].numpy(), dets8[3][i].numpy()) for i in range(8) if dets8[0][i] is not None]
     nobj = sum(len(c) for c, _ in objs)
@@ -134,10 +188,12 @@ def cpu_baseline(backbone, sd, H, W, cfg, full=False):
         detail['decode3d scipy threads=1'] = {'objects': cnt, 'best_s': best, 'median_s': med, 'objects_per_s_best': cnt / best}
     fw = max(detail['forward+decode2d bs=%d threads=%d' % (bs, nthreads)]['images_per_s_best'] for bs in (1, 8))
     per_img = 1.0 / fw + (per_obj or 0.0) * nobj / 8.0
-    return {'value': 1.0 / per_img, 'unit': 'images/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%s %dx%d fp32 PyTorch-CPU oracle: forward+2D decode bs=1 and bs=8 (1 warm-up + 3 timed, best) on %d threads, '
+    return {'value': 1.0 / per_img, 'unit': 'images/s', 'cores': nthreads, 'kind': 'port', 'host': host,
+            'sample': '%s %dx%d fp32 PyTorch-CPU oracle: forward+2D decode bs=1 and bs=8 (1 warm-up + 3 timed, best) on %d threads '
+                      '(= min(affinity %d, cgroup quota %s) of a %s), '
                       '+ SciPy L-BFGS-B 3D decode at %.1f objects/image (measured on %d objects, 3 runs, 1 thread); '
-                      'one-thread forward timed beside it' % (backbone, H, W, nthreads, nobj / 8.0, cnt if ts else 0),
+                      'one-thread forward timed beside it' % (backbone, H, W, nthreads, host['affinity'], host['cgroup_cpu_quota'],
+                                                              host['cpu_model'], nobj / 8.0, cnt if ts else 0),
             'detail': detail}
 
 
@@ -578,7 +634,7 @@ def main():
                                                          i['bytes'] / i['ms'] / 1e6 if i['ms'] else 0), file=sys.stderr)
             print('forward total %.3f ms (per-op event timing)' % tot, file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, cfg, full=args.cpu_full)
+            out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, cfg, full=args.cpu_full, threads=args.cpu_threads)
         else:
             out['cpu_baseline'] = None
         if not args.no_parity and world == 1 and not args.from_uint8:

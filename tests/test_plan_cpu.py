@@ -1,5 +1,7 @@
 """CPU: the host-side plan (graph wiring without torch.cat, BN folding, deconv phases, weight
 packing) reproduces the oracle; and fp16 storage keeps logits within the stated tolerance."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -78,6 +80,35 @@ def test_weight_cache_is_transparent_and_persistent(tmp_path):
     sd2 = dict(sd); sd2['backbone.conv1.weight'] = sd['backbone.conv1.weight'] + 1
     assert state_dict_digest(sd2) != state_dict_digest(sd)
     assert WeightCache(sd2, directory=str(tmp_path)).entries == {}
+
+
+def test_weight_cache_rejects_other_formats_and_corrupt_files(tmp_path, monkeypatch):
+    """the on-disk cache is keyed by the state dict AND the pack-format tag (format version, C ABI version, hash of
+    the packing code): a file written by another build of the packers is never read back; a truncated / corrupt file is
+    ignored and replaced; temporary files are private to the writer and do not stay behind."""
+    from rtm3d_amd import weight_cache as wc
+    sd = weights.synth_state_dict('RESNET-18', 3, 'trained')
+    c = wc.WeightCache(sd, directory=str(tmp_path))
+    plan_mod.build_plan(sd, 'RESNET-18', 1, 64, 128, cache=c)
+    path = c.save()
+    assert path and os.path.exists(path) and [f for f in os.listdir(str(tmp_path)) if 'tmp' in f] == []
+    assert wc.WeightCache(sd, directory=str(tmp_path)).entries            # same format: served
+    # another pack format: different digest -> different file, nothing loaded
+    monkeypatch.setattr(wc, 'PACK_FORMAT_VERSION', wc.PACK_FORMAT_VERSION + 1)
+    c_new = wc.WeightCache(sd, directory=str(tmp_path))
+    assert c_new.entries == {} and c_new.digest != c.digest and c_new._path() != path
+    # even a file that was renamed onto the new digest's path is refused by its own format field
+    os.replace(path, c_new._path())
+    assert wc.WeightCache(sd, directory=str(tmp_path)).entries == {}
+    monkeypatch.undo()
+    # corrupt / truncated file under the right name: ignored, recomputed, replaced
+    c3 = wc.WeightCache(sd, directory=str(tmp_path))
+    with open(c3._path(), 'wb') as f:
+        f.write(b'PK\x03\x04 not a zip')
+    c4 = wc.WeightCache(sd, directory=str(tmp_path))
+    assert c4.entries == {}
+    plan_mod.build_plan(sd, 'RESNET-18', 1, 64, 128, cache=c4)
+    assert c4.save() and wc.WeightCache(sd, directory=str(tmp_path)).entries
 
 
 def test_halo_kernel_selection():
