@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 4
+#define RTM3D_ABI_VERSION 5
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -140,6 +140,10 @@ int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const 
  * (d_in, d_out_logits[0..3]) pointer tuple - kernel arguments are baked into it - and up to 8 tuples are cached (LRU).
  * Results are bit-identical to the eager replay.  The live probe (rtm3d_probe_set) forces the eager path.            */
 int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable);
+/* Graph bookkeeping of a context: captures made, replays served from the cache, whether graph mode is still on (a caller that
+ * hands over fresh buffers on every call makes every call a capture; after 32 captures without as many hits the context gives
+ * up on graphs - Model.forward_logits(out=...) keeps the addresses stable).  Any pointer may be NULL.                      */
+int rtm3d_ctx_graph_stats(rtm3d_ctx* ctx, int* captures, int* hits, int* enabled);
 
 /* Per-op timing of one replay with hipEvents (synchronous; for profiling/bench):
  * h_ms[i] = elapsed ms of op i; returns number of ops through *n_ops (h_ms may be NULL).          */
@@ -182,7 +186,8 @@ int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_f
  *   d_cls[N] int64, d_verts[N*16] fp32, d_K[N*9] fp64 (row-major 3x3 per object),
  *   d_dim_ref[ncls*3] fp64 (h,w,l), d_ref_loc[3] fp64.
  * Outputs: d_x[N*8] fp64 final iterate, d_fun[N] fp64, d_nit[N] int32, d_status[N] int32
- * (0 converged, 1 max iterations, 2 abnormal line search).  The caller applies `fun < 0.1`.       */
+ * (0 converged, 1 max iterations, 2 abnormal line search, 3 non-finite objective at the start point:
+ * NaN / Inf key points give x = x0, fun = NaN, nit = 0 like SciPy does).  The caller applies `fun < 0.1`. */
 int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                    const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                    double* d_fun, int32_t* d_nit, int32_t* d_status);

@@ -177,6 +177,9 @@ struct LbSearch {
 enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2, LS_ERROR = 3 };
 
 LB_HD static inline double lb_max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
+// status of a start point whose objective or gradient is NaN / Inf (0 converged, 1 iteration limit, 2 abnormal line search)
+#define LB_STATUS_NONFINITE 3
+LB_HD static inline bool lb_isfinite(double v) { return (v - v) == 0.0; }      // false for NaN and +-Inf, no libm call
 
 LB_HD static inline void lb_dcstep(double* stx, double* fx, double* dx, double* sty, double* fy, double* dy,
                                    double* stp, double fp, double dp, int* brackt, double stpmin, double stpmax) {
@@ -514,6 +517,14 @@ LB_HD static inline int lb_minimize(const LbProblem* prob, double* x, double* f_
     LbSearch S;
 
     f = lb_fun(prob, x); lb_grad(prob, x, g); nfgv = 1;
+    // Non-finite key points (NaN / Inf logits upstream): the objective is not a number at the start point.  SciPy returns
+    // x0 with fun = nan after 0 iterations there (the oracle run on such vertices); so does this, with its own status, instead
+    // of feeding NaNs to the line search (fmax below would drop them and compare garbage).
+    {
+        bool finite = lb_isfinite(f);
+        for (int i = 0; i < n; ++i) finite = finite && lb_isfinite(g[i]);
+        if (!finite) { *f_out = f; *nit_out = 0; return LB_STATUS_NONFINITE; }
+    }
     sbgnrm = 0.0;
     for (int i = 0; i < n; ++i) sbgnrm = fmax(sbgnrm, fabs(g[i]));
     if (sbgnrm <= pgtol) { *f_out = f; *nit_out = 0; return 0; }

@@ -186,6 +186,11 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
     const long long tstart_ = __builtin_readcyclecounter();
 #endif
     f = lbw_fg(w, K, lane); nfgv = 1;
+    {   // non-finite key points: x0, fun = NaN / Inf, 0 iterations, own status (see lb_minimize)
+        bool finite = lb_isfinite(f);
+        for (int i = 0; i < n; ++i) finite = finite && lb_isfinite(w->g[i]);
+        if (!finite) { *f_out = f; *nit_out = 0; return LB_STATUS_NONFINITE; }
+    }
     sbgnrm = 0.0;
     for (int i = 0; i < n; ++i) sbgnrm = fmax(sbgnrm, fabs(w->g[i]));
     if (sbgnrm <= pgtol) { *f_out = f; *nit_out = 0; return 0; }

@@ -243,6 +243,10 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         if (res) {
             if (d->res_coff[g] < 0 || d->res_coff[g] + d->cout > res->C || (d->res_coff[g] % 8)) RT_FAIL("op_conv: residual channel slice out of range");
             if (oyhi >= res->H || oxhi >= res->W) RT_FAIL("op_conv: residual pixel out of range");
+            // a residual must not alias the output ("in place"): partial pixel tiles are padded with copies of their last pixel,
+            // and a copy that loads the residual after another copy has stored would add it twice
+            if (out && res == out && d->res_coff[g] < d->out_coff[g] + d->cout && d->out_coff[g] < d->res_coff[g] + d->cout)
+                RT_FAIL("op_conv: the residual channel slice [%d,%d) overlaps the output slice [%d,%d) of the same tensor", d->res_coff[g], d->res_coff[g] + d->cout, d->out_coff[g], d->out_coff[g] + d->cout);
         }
         a.g[g].in_coff = d->in_coff[g]; a.g[g].out_coff = d->out_coff[g]; a.g[g].res_coff = d->res_coff[g];
         a.g[g].out_oy = d->out_oy[g]; a.g[g].out_ox = d->out_ox[g];
@@ -622,18 +626,29 @@ static const size_t GRAPH_CACHE = 8;
 
 static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4]);
 
+// Replays of one context never overlap: the workspace and the ticket counters are shared.  Every replay (rtm3d_forward and
+// rtm3d_forward_timed alike) is bracketed by these two: a replay on another stream than the previous one waits for it.
+static int replay_begin(rtm3d_ctx* ctx, hipStream_t s) {
+    if (ctx->has_last && ctx->last_stream != s) RT_HIP(hipStreamWaitEvent(s, ctx->done_ev, 0));
+    return 0;
+}
+static int replay_end(rtm3d_ctx* ctx, hipStream_t s) {
+    if (!ctx->done_ev) RT_HIP(hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
+    RT_HIP(hipEventRecord(ctx->done_ev, s));
+    ctx->last_stream = s; ctx->has_last = true;
+    return 0;
+}
+
 extern "C" int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4]) {
     if (!ctx || !d_out_logits) RT_FAIL("forward: null argument");
     if (!d_out_logits[0]) RT_FAIL("forward: null logits buffer 0");
     if (ctx->ops.empty()) RT_FAIL("forward: empty plan");
     hipStream_t s = (hipStream_t)stream;
-    // the previous replay ran on another stream: order this one behind it (the workspace and the ticket counters are shared)
-    if (ctx->has_last && ctx->last_stream != s) RT_HIP(hipStreamWaitEvent(s, ctx->done_ev, 0));
-    if (forward_on_stream(ctx, s, d_in, d_out_logits)) return 1;
-    if (!ctx->done_ev) RT_HIP(hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
-    RT_HIP(hipEventRecord(ctx->done_ev, s));
-    ctx->last_stream = s; ctx->has_last = true;
-    return 0;
+    if (replay_begin(ctx, s)) return 1;
+    const int rc = forward_on_stream(ctx, s, d_in, d_out_logits);
+    // recorded even after a failed replay: whatever part of it was enqueued still owns the workspace
+    if (replay_end(ctx, s)) return 1;
+    return rc;
 }
 
 static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4]) {
@@ -657,7 +672,8 @@ static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, f
     rtm3d_ctx::GraphEntry ge;
     memcpy(ge.key, key, sizeof(key));
     ge.graph = graph;
-    RT_HIP(hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+    const hipError_t ei = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { (void)hipGraphDestroy(graph); rt_set_error("forward: hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return 1; }
     ge.last_use = ctx->graph_clock;
     if (ctx->graphs.size() >= GRAPH_CACHE) {            // evict the least recently used entry
         size_t lru = 0;
@@ -684,6 +700,14 @@ extern "C" int rtm3d_input_tensor(rtm3d_ctx* ctx, void** d_base, int* B, int* H,
 extern "C" int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable) {
     if (!ctx) RT_FAIL("ctx_set_graph: null context");
     ctx->graph_mode = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int rtm3d_ctx_graph_stats(rtm3d_ctx* ctx, int* captures, int* hits, int* enabled) {
+    if (!ctx) RT_FAIL("ctx_graph_stats: null context");
+    if (captures) *captures = (int)ctx->graph_captures;
+    if (hits) *hits = (int)ctx->graph_hits;
+    if (enabled) *enabled = ctx->graph_mode;
     return 0;
 }
 
@@ -720,19 +744,29 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     if (n_ops) *n_ops = n;
     if (!h_ms) return 0;
     if (cap < n) RT_FAIL("forward_timed: capacity %d < %d ops", cap, n);
-    std::vector<hipEvent_t> ev(n + 1);
-    for (auto& e : ev) RT_HIP(hipEventCreate(&e));
+    if (!d_out_logits[0]) RT_FAIL("forward_timed: null logits buffer 0");
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
     hipStream_t s = (hipStream_t)stream;
-    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s));
-    RT_HIP(hipEventRecord(ev[0], s));
-    for (int i = 0; i < n; ++i) {
-        if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) return 1;
-        RT_HIP(hipEventRecord(ev[i + 1], s));
+    // same ordering rule as rtm3d_forward (the timed pass shares the workspace and the ticket counters with it); the events
+    // are destroyed on every path out
+    int rc = 0;
+    hipError_t e = hipSuccess;
+    for (auto& v : ev) if ((e = hipEventCreate(&v)) != hipSuccess) { rc = 1; break; }
+    if (!rc && replay_begin(ctx, s)) rc = 2;
+    if (!rc) {
+        if (ctx->tile_ctr && (e = hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s)) != hipSuccess) rc = 1;
+        if (!rc && (e = hipEventRecord(ev[0], s)) != hipSuccess) rc = 1;
+        for (int i = 0; i < n && !rc; ++i) {
+            if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) { rc = 2; break; }
+            if ((e = hipEventRecord(ev[i + 1], s)) != hipSuccess) rc = 1;
+        }
+        if (replay_end(ctx, s) && !rc) rc = 2;
+        if (!rc && (e = hipEventSynchronize(ev[n])) != hipSuccess) rc = 1;
+        for (int i = 0; i < n && !rc; ++i) if ((e = hipEventElapsedTime(&h_ms[i], ev[i], ev[i + 1])) != hipSuccess) rc = 1;
     }
-    RT_HIP(hipEventSynchronize(ev[n]));
-    for (int i = 0; i < n; ++i) RT_HIP(hipEventElapsedTime(&h_ms[i], ev[i], ev[i + 1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    return 0;
+    for (auto& v : ev) if (v) (void)hipEventDestroy(v);
+    if (rc == 1) rt_set_error("forward_timed: %s", hipGetErrorString(e));
+    return rc ? 1 : 0;
 }
 
 extern "C" int rtm3d_op_info(rtm3d_ctx* ctx, int i, double* flops, double* bytes, const char** name) {

@@ -181,9 +181,14 @@ class Model(object):
         dev = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
         return self._plan_for(B, H, W, dev).input_tensor()
 
-    def forward_logits(self, x, preloaded=None):
+    def forward_logits(self, x, preloaded=None, out=None):
         """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23).
-        preloaded=(B, H, W): ``x`` is None and the plan's input tensor was filled by preprocess_batch(model=self)."""
+        preloaded=(B, H, W): ``x`` is None and the plan's input tensor was filled by preprocess_batch(model=self).
+        out: where the logits go instead of four fresh tensors - a tuple of contiguous fp32 CUDA tensors of the logit
+        shapes, or ``'reuse'`` for one set of buffers owned by the plan of this shape (every such call returns the SAME
+        tensors: consume them, in stream order, before the next call).  A hipGraph replay is keyed by these addresses
+        (rtm3d_forward), so a loop that holds on to its fresh outputs would pay a capture per call; with out= it replays one
+        graph (the bs=1 detect.py loop)."""
         if preloaded is not None:
             if x is not None:
                 raise ValueError('forward_logits: pass x=None with preloaded=(B, H, W)')
@@ -199,7 +204,23 @@ class Model(object):
             xptr = x.data_ptr()
         plan = self._plan_for(B, H, W, dev)
         with torch.cuda.device(dev):
-            outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in self._head_channels]
+            shapes = [(B, c, H // 4, W // 4) for c in self._head_channels]
+            if out is None:
+                outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+            elif isinstance(out, str):
+                if out != 'reuse':
+                    raise ValueError("forward_logits: out must be a tuple of tensors or 'reuse'")
+                outs = getattr(plan, 'logit_buffers', None)
+                if outs is None:
+                    outs = plan.logit_buffers = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+            else:
+                outs = list(out)
+                if len(outs) != len(shapes):
+                    raise ValueError('forward_logits: out needs %d tensors, got %d' % (len(shapes), len(outs)))
+                for t, sh in zip(outs, shapes):
+                    if not isinstance(t, torch.Tensor) or tuple(t.shape) != sh or t.dtype != torch.float32 or not t.is_cuda \
+                            or (dev.index is not None and t.device.index != dev.index) or not t.is_contiguous():
+                        raise ValueError('forward_logits: out tensors must be contiguous fp32 %s on %s' % (shapes, dev))
             ptrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
             plan.forward(torch.cuda.current_stream(dev).cuda_stream, xptr, ptrs)
         return tuple(outs)

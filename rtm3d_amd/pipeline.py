@@ -101,7 +101,7 @@ class Detect3DPipeline(object):
 
         def feed():
             preprocess.preprocess_batch(images, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=resize_to, model=self.model)
-            return self.model.forward_logits(None, preloaded=(self.B, H, W))
+            return self.model.forward_logits(None, preloaded=(self.B, H, W), out='reuse')
         return self._submit(feed, K_per_image)
 
     def submit(self, x, K_per_image):
@@ -112,7 +112,7 @@ class Detect3DPipeline(object):
             # rtm3d_amd.distributed.padded_shard)
             raise ValueError('Detect3DPipeline was built for batches of %d images, got input of shape %s'
                              % (self.B, tuple(x.shape)))
-        return self._submit(lambda: self.model.forward_logits(x), K_per_image)
+        return self._submit(lambda: self.model.forward_logits(x, out='reuse'), K_per_image)
 
     def _submit(self, run_network, K_per_image):
         if not isinstance(K_per_image, torch.Tensor) or K_per_image.numel() != self.B * 9 or not K_per_image.is_cuda:

@@ -814,6 +814,12 @@ class RealizedPlan(object):
         """Replay the plan as one hipGraph launch (bit-identical results; see rtm3d_ctx_set_graph)."""
         _lib.check(self.lib.rtm3d_ctx_set_graph(self.ctx, 1 if enable else 0), 'ctx_set_graph')
 
+    def graph_stats(self):
+        """(captures, cache hits, graph mode still enabled) of this context (rtm3d_ctx_graph_stats)."""
+        c, h, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.rtm3d_ctx_graph_stats(self.ctx, ctypes.byref(c), ctypes.byref(h), ctypes.byref(e)), 'ctx_graph_stats')
+        return c.value, h.value, bool(e.value)
+
     def probe_set(self, op_index):
         _lib.check(self.lib.rtm3d_probe_set(self.ctx, int(op_index)), 'probe_set')
 

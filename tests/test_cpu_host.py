@@ -75,6 +75,31 @@ def test_lbfgsb_direct_form_on_reference_kept_objects(built):
     assert n_kept >= 50 and n_all >= 200
 
 
+@pytest.mark.parametrize('form', ['lb_solve_batch', 'lb_solve_batch_direct'])
+def test_lbfgsb_nonfinite_vertices_follow_scipy(built, form):
+    """NaN / Inf key points (non-finite logits upstream): the reference's SciPy call returns x0, fun = nan, nit = 0 and the
+    object is rejected (nan < 0.1 is False); the product solver does the same with status 3 and no iterations, instead of
+    walking a NaN line search up to the iteration limit.  Finite neighbours in the same batch are unaffected."""
+    from oracle import decode3d_ref
+    from tests.golden.cases import DIM_REF
+    lib = ctypes.CDLL(os.path.join(REPO, 'tests', '_build', 'libhost_lbfgsb.so'))
+    g = load_golden('decode3d_cases.npz')
+    N = 6
+    cls = np.ascontiguousarray(g['clses'][:N], np.int64); uv = np.ascontiguousarray(g['uv'][:N], np.float32).copy()
+    uv[1, 3] = np.nan; uv[3, 0] = np.inf; uv[4, :] = -np.inf
+    K = np.ascontiguousarray(np.tile(g['K'], (N, 1))); dim = np.ascontiguousarray(g['dim_ref']); loc = np.ascontiguousarray(g['ref_loc'])
+    x = np.zeros((N, 8)); f = np.zeros(N); nit = np.full(N, -7, np.int32); st = np.full(N, -7, np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    getattr(lib, form)(N, P(cls), P(uv), P(K), P(dim), P(loc), P(x), P(f), P(nit), P(st))
+    _, raw = decode3d_ref.optim_decode_bbox3d(cls, uv.reshape(N, 8, 2), g['K'].reshape(3, 3), g['dim_ref'], g['ref_loc'], return_raw=True)
+    bad = np.array([False, True, False, True, True, False])
+    assert (st[bad] == 3).all() and (nit[bad] == 0).all() and not np.isfinite(f[bad]).any()
+    assert (raw['nit'][bad] == 0).all() and np.isnan(raw['fun'][bad]).all() and not raw['kept'][bad].any()
+    np.testing.assert_array_equal(x[bad], raw['x'][bad])                       # x0, like the reference
+    assert (st[~bad] != 3).all()
+    np.testing.assert_allclose(x[~bad], g['raw_x'][:N][~bad], rtol=0, atol=1e-4)
+
+
 def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(REPO, 'include', 'rtm3d_hip.h')).read()
     declared = set(re.findall(r'\b(rtm3d_[a-z0-9_]+)\s*\(', hdr))

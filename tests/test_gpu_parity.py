@@ -579,6 +579,60 @@ def test_pack_records_hip_equals_reference(dev):
         rdist.pack_records(n, cls, score, mproj, verts, bbox, topk)          # CPU tensors: no CPU path
 
 
+def test_nonfinite_logits_through_decode2d_decode3d_pack(dev):
+    """NaN / Inf logits and key points through decode2d -> decode3d -> pack, against the oracle on the
+    same arrays: a NaN heat-map cell is no peak on either side (NaN > thresh is False), a +Inf cell is a peak with score 1;
+    NaN / Inf regression values at a peak give non-finite vertices, for which the solver stops at once with status 3, x = x0,
+    fun = NaN, nit = 0 (what SciPy returns), the record carries flag 1 (2D only) and no kept box; finite objects of the same
+    image are solved as usual.  The launch terminates (bounded work per object: 0 iterations)."""
+    from rtm3d_amd import distributed as rdist
+    from rtm3d_amd.model_utils import decode3d_slots
+    g = load_golden('planted_small.npz')
+    th, tk, K, arrs, _ = planted_inputs('planted_small', load_golden(PLANTED_CASES['planted_small'][0]))
+    arrs = [a[:1].copy() for a in arrs]
+    d0 = rtm3d_ref.inference([torch.from_numpy(a) for a in arrs], th, tk, 4.0)
+    n0 = len(d0[0][0])
+    cells = (d0[2][0].numpy() // 4).astype(int)                     # (n, 2) = x, y of every peak
+    # poison: NaN vertex offsets at peak 0, +Inf at peak 1, NaN main offset at peak 2; heat map: one NaN cell that was a
+    # peak (peak 3 disappears), one +Inf cell somewhere else (a new peak with score 1)
+    x0_, y0_ = cells[0]; arrs[1][0, 3, y0_, x0_] = np.nan
+    x1_, y1_ = cells[1]; arrs[1][0, 0, y1_, x1_] = np.inf
+    x2_, y2_ = cells[2]; arrs[2][0, 1, y2_, x2_] = np.nan
+    x3_, y3_ = cells[3]; arrs[0][0, int(d0[0][0][3]), y3_, x3_] = np.nan
+    arrs[0][0, 1, 5, 7] = np.inf
+    d_ref = rtm3d_ref.inference([torch.from_numpy(a) for a in arrs], th, tk, 4.0)
+    m = make_model('DLA-34', None, th, tk)
+    det = m.decode2d([torch.from_numpy(a).to(dev) for a in arrs])
+    Kd = torch.as_tensor(K.reshape(1, 9), device=dev)
+    bx = decode3d_slots(det, Kd, m.config.DETECTOR.dim_ref, [0, -0.5, 20])
+    rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, tk, bx)
+    torch.cuda.synchronize()
+    n = int(det.n.item())
+    assert n == len(d_ref[0][0]) and n in (n0, n0 + 1, n0 - 1)
+    # detections: same classes and cells; finite fields bit-exact, non-finite ones non-finite in the same places
+    assert torch.equal(det.cls[:n].cpu(), d_ref[0][0])
+    for got, ref in ((det.score[:n], d_ref[1][0]), (det.mproj[:n], d_ref[2][0]), (det.verts[:n], d_ref[3][0])):
+        got, ref = got.cpu().numpy(), ref.numpy()
+        np.testing.assert_array_equal(np.isfinite(got), np.isfinite(ref))
+        np.testing.assert_array_equal(got[np.isfinite(ref)], ref[np.isfinite(ref)])
+    assert float(det.score[:n].max()) == 1.0                        # the +Inf cell
+    verts = det.verts[:n].cpu().numpy().reshape(n, 16)
+    bad = ~np.isfinite(verts).all(1)
+    assert 2 <= bad.sum() <= 3
+    st, fun, nit, xs = (t[:n].cpu().numpy() for t in (bx.status, bx.fun, bx.nit, bx.x))
+    assert (st[bad] == 3).all() and (nit[bad] == 0).all() and not np.isfinite(fun[bad]).any()
+    _, raw = decode3d_ref.optim_decode_bbox3d(d_ref[0][0].numpy(), d_ref[3][0].numpy(), K, m.config.DETECTOR.dim_ref, [0, -0.5, 20],
+                                              return_raw=True)
+    assert (raw['nit'][bad] == 0).all() and not raw['kept'][bad].any()
+    np.testing.assert_array_equal(xs[bad], raw['x'][bad])
+    np.testing.assert_array_equal(fun[~bad] < 0.1, raw['kept'][~bad])
+    good_kept = (~bad) & raw['kept']
+    assert good_kept.sum() >= 5
+    np.testing.assert_allclose(xs[good_kept], raw['x'][good_kept], rtol=0, atol=1e-4)
+    r = rec[0, :n].cpu().numpy()
+    assert (r[bad, 31] == 1).all() and (r[good_kept, 31] == 2).all() and (rec[0, n:] == 0).all()
+
+
 def test_pipeline_rejects_wrong_batch(dev):
     """a shard larger than the preallocated slots would be an out-of-bounds device write, a smaller one
     would leave stale detections in the unused rows - both must raise before anything is launched."""
@@ -661,6 +715,44 @@ def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
     a = mg.forward_logits(xs[1]); b = me.forward_logits(xs[1])      # the first shape was evicted and is rebuilt
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_forward_logits_out_keeps_one_graph(dev):
+    """a bs=1 loop that HOLDS its outputs gets fresh logit tensors on every call, i.e. a new graph key and
+    a capture per call until the context gives up on graphs after 32; with out='reuse' (or explicit out= tensors) the same
+    loop replays ONE captured graph.  Logits are bit-identical on both routes."""
+    sd = weights.synth_state_dict('RESNET-18', 1, 'trained', heat_bias=-3.0)
+    x = weights.synth_images(1, 64, 128, seed=77).to(dev)
+    m = make_model('RESNET-18', sd)
+    m.use_graph = True
+    ref = [t.clone() for t in m.forward_logits(x)]
+    held = []
+    for _ in range(40):
+        held.append(m.forward_logits(x))                  # the trap: 40 live output sets = 40 distinct keys
+    torch.cuda.synchronize()
+    plan = m._plan_for(1, 64, 128, dev)
+    cap, hits, on = plan.graph_stats()
+    assert cap > 32 and not on                            # gave up: eager replay from here on
+    for a, b in zip(held[-1], ref):
+        assert torch.equal(a, b)
+    m2 = make_model('RESNET-18', sd)
+    m2.use_graph = True
+    held = []
+    for _ in range(40):
+        lg = m2.forward_logits(x, out='reuse')
+        held.append(lg[0].data_ptr())
+    mine = [torch.empty_like(t) for t in ref]
+    for _ in range(5):
+        lg2 = m2.forward_logits(x, out=mine)
+    torch.cuda.synchronize()
+    cap, hits, on = m2._plan_for(1, 64, 128, dev).graph_stats()
+    assert len(set(held)) == 1 and cap == 2 and hits == 43 and on
+    for a, b, c in zip(lg, lg2, ref):
+        assert torch.equal(a, c) and torch.equal(b, c)
+    with pytest.raises(ValueError):
+        m2.forward_logits(x, out=mine[:2])
+    with pytest.raises(ValueError):
+        m2.forward_logits(x, out=[t.double() for t in mine])
 
 
 def test_class_count_follows_dataset_objs(dev):
