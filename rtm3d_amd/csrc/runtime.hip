@@ -606,11 +606,25 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
     return 0;
 }
 
+// Zeroes the ticket / arrival counters.  A kernel of our own instead of hipMemsetAsync: inside a captured graph the memset
+// becomes a memset NODE, and with three or more graph execs of different node counts alive in one context, re-launching an
+// older exec ran the kernel node BEHIND that memset node with stale arguments (round 3: the fp32 -> NHWC4 conversion of one
+// graph had no effect, the first convolution of another faulted on an unmapped address; all-kernel graphs alternate fine).
+__global__ void zero_words_kernel(unsigned int* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static hipError_t zero_counters(rtm3d_ctx* ctx, hipStream_t s) {
+    if (!ctx->tile_ctr) return hipSuccess;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(((int)TILE_CTR_WORDS + 255) / 256), dim3(256), 0, s, ctx->tile_ctr, (int)TILE_CTR_WORDS);
+    return hipGetLastError();
+}
+
 static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4], bool probes) {
     // The persistent convs share 8 self-resetting ticket counters; after an aborted launch (or a replay torn down half
     // way) they would be left non-zero and later launches would silently skip tiles.  Zeroing them in stream order at
-    // the head of every replay costs one 32-byte memset node.
-    if (ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s));
+    // the head of every replay costs one tiny launch (zero_counters).
+    RT_HIP(zero_counters(ctx, s));
     const int n = (int)ctx->ops.size();
     for (int i = 0; i < n; ++i) {
         const bool probe = probes && (i == ctx->probe_op);
@@ -754,7 +768,7 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     for (auto& v : ev) if ((e = hipEventCreate(&v)) != hipSuccess) { rc = 1; break; }
     if (!rc && replay_begin(ctx, s)) rc = 2;
     if (!rc) {
-        if (ctx->tile_ctr && (e = hipMemsetAsync(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int), s)) != hipSuccess) rc = 1;
+        if ((e = zero_counters(ctx, s)) != hipSuccess) rc = 1;
         if (!rc && (e = hipEventRecord(ev[0], s)) != hipSuccess) rc = 1;
         for (int i = 0; i < n && !rc; ++i) {
             if (launch_op(ctx, ctx->ops[i], s, d_in, d_out_logits)) { rc = 2; break; }

@@ -717,6 +717,17 @@ def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize('bb,B,H,W', [('RESNET-18', 3, 128, 256), ('DLA-34', 1, 64, 128)])
+def test_graph_relaunch_orders_of_mixed_structure(dev, bb, B, H, W):
+    """One context, up to eight live graph execs of two structures (fp32 input: with the NHWC4 conversion node; preloaded uint8
+    input: without it) and several input / output addresses, captured and re-launched in the orders that failed in round 3
+    while the counter reset was a hipMemsetAsync NODE (n, n, n-1 nodes -> re-launch the first: its conversion kernel had no
+    effect; n, n-1, n -> re-launch the second: memory access fault in its first convolution) and in a seeded random order;
+    every result equals the eager replay bit for bit (tools/gpu_graph_stress.py)."""
+    from tools.gpu_graph_stress import run
+    assert run(lambda s: None, bb, B, H, W, rounds=30) == 0
+
+
 def test_forward_logits_out_keeps_one_graph(dev):
     """a bs=1 loop that HOLDS its outputs gets fresh logit tensors on every call, i.e. a new graph key and
     a capture per call until the context gives up on graphs after 32; with out='reuse' (or explicit out= tensors) the same
