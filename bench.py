@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument('--cpu-full', action='store_true', help='whole BASELINE.md section-4 CPU protocol (adds minutes: one-thread bs=8)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the all-thread CPU legs (0: min(scheduler affinity, cgroup CPU quota))')
     ap.add_argument('--no-parity', action='store_true', help='skip the 3D-box L-inf check against the CPU oracle')
-    ap.add_argument('--parity-images', type=int, default=2)
+    ap.add_argument('--parity-images', type=int, default=8, help='benchmark images the oracle runs for the parity block (16 planted cuboids each)')
     ap.add_argument('--side-cus', type=int, default=0, help='CUs the decode3d side stream may use (0 = unrestricted)')
     ap.add_argument('--depth', type=int, default=0, help='pipeline slots (0: automatic)')
     ap.add_argument('--side-streams', type=int, default=0, help='decode3d side streams (0: automatic)')
@@ -64,6 +64,7 @@ def parse_args():
                          'normalise on the device (two launches, straight into the fp16 input tensor) in front of the plan; once: the same images are '
                          'preprocessed once, outside the timed region, into the fp32 NCHW batch that is then fed like the BASELINE line (the A/B partner)')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
+    ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
     ap.add_argument('--dry-launch', action='store_true', help='launcher rehearsal over gloo on CPU tensors, no GPU and no hot path (line marked INVALID)')
@@ -197,19 +198,49 @@ def cpu_baseline(backbone, sd, H, W, cfg, full=False, threads=None):
             'detail': detail}
 
 
-def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
+def _dist(values, bar=1e-4):
+    """p50 / p90 / p99 / max and the share at or below the bar of a 1-D sample."""
+    v = np.asarray(values, np.float64)
+    if v.size == 0:
+        return None
+    q = np.percentile(v, [50, 90, 99])
+    return {'n': int(v.size), 'p50': float(q[0]), 'p90': float(q[1]), 'p99': float(q[2]), 'max': float(v.max()),
+            'frac_le_%g' % bar: float((v <= bar).mean())}
+
+
+BOX_PARAMS = ['Ry', 'h', 'w', 'l', 'X', 'Y', 'Z']
+
+
+def _box_stats(boxd):
+    """boxd: list of (7,) |device - reference| per box over [Ry, h, w, l, X, Y, Z].  Per-box L-inf distribution + the same
+    per parameter."""
+    if not boxd:
+        return None
+    bd = np.stack(boxd)
+    out = {'box_linf': _dist(bd.max(1))}
+    out['per_param'] = {n: {k: v for k, v in _dist(bd[:, i]).items() if k != 'n'} for i, n in enumerate(BOX_PARAMS)}
+    return out
+
+
+def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2):
     """BASELINE metric, second half: 3D-box L-inf of the device pipeline vs the CPU reference path (the oracle), on
     the first k images of the benchmark workload (`x_dev` = the benchmark batch: the device runs the SAME plan / kernels
-    as the timed steps on the whole batch, the oracle the first k images of it).  Two regimes:
+    as the timed steps on the whole batch, the oracle the first k images of it).  Regimes:
       stage : the device decode kernels fed the ORACLE's fp32 logits, with `planted` exact cuboid projections per image
               written over them (tests/golden/cases.plant_cuboids) so that real boxes are kept (fun < 0.1) next to the
               workload's natural detections: indices must be identical, boxes are compared on the kept objects;
       e2e   : images -> fp16 network -> device decode, against the fp32 oracle end to end: detections matched by
-              (class, y, x) cell, vertex / score L-inf on the matches, box L-inf on the objects BOTH sides keep."""
+              (class, y, x) cell, vertex / score L-inf on the matches, box |d| on the objects BOTH sides keep: per-box L-inf
+              and per-parameter p50 / p90 / p99 / max and the share within 1e-4 (north_star's bar);
+      e2e_fp32_mode : the same with the network in the fp32 verification mode;
+      reference_sensitivity : the REFERENCE's own decode (SciPy, through the oracle) re-run on its own kept objects with
+              the vertices moved by uniform noise of the vertex error each mode was measured at: how far the reference
+              itself moves for an input error of that size (the yardstick for the two e2e distributions)."""
     from oracle import rtm3d_ref, decode3d_ref
     from rtm3d_amd import weights
     from rtm3d_amd.model_utils import decode3d_slots
     from tests.golden.cases import plant_cuboids
+    t_start = time.perf_counter()
     th, tk = float(cfg.DETECTOR.SCORE_THRESH), int(cfg.DETECTOR.TOPK_CANDIDATES)
     dim_ref = cfg.DETECTOR.dim_ref
     k = min(k, x_dev.shape[0])
@@ -217,7 +248,13 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     K = weights.synth_intrinsics()
     Kd = torch.as_tensor(np.tile(K, (k, 1)), dtype=torch.float64, device=dev)
     Kd_all = torch.as_tensor(np.tile(K, (x_dev.shape[0], 1)), dtype=torch.float64, device=dev)
-    dets_ref, logits_ref = rtm3d_ref.model_forward(x, sd, backbone, th, tk)
+    host = host_cpu_info()
+    torch_default = torch.get_num_threads()
+    torch.set_num_threads(host['usable'])
+    try:
+        dets_ref, logits_ref = rtm3d_ref.model_forward(x, sd, backbone, th, tk)
+    finally:
+        torch.set_num_threads(torch_default)
 
     def box_params(xs):            # (n, 8) solver state -> (n, 7) [Ry, h, w, l, X, Y, Z]  (utils/model_utils.py:300-303)
         return np.concatenate([np.arctan2(xs[:, 0:1], xs[:, 1:2]), xs[:, 3:5], xs[:, 2:3], xs[:, 5:8]], 1)
@@ -227,11 +264,13 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
         d[:, 0] = np.minimum(d[:, 0], 2 * np.pi - d[:, 0])
         return d
 
-    def solve_ref(dets, b):
-        _, raw = decode3d_ref.optim_decode_bbox3d(dets[0][b].numpy(), dets[3][b].numpy(), K, dim_ref, [0, -0.5, 20], return_raw=True)
+    def solve_ref(dets, b, verts=None):
+        v = dets[3][b].numpy() if verts is None else verts
+        _, raw = decode3d_ref.optim_decode_bbox3d(dets[0][b].numpy(), v, K, dim_ref, [0, -0.5, 20], return_raw=True)
         return raw
 
-    out = {'images': k, 'reference': 'oracle: PyTorch-CPU fp32 forward + Model.inference restatement + SciPy L-BFGS-B'}
+    out = {'images': k, 'planted_per_image': planted,
+           'reference': 'oracle: PyTorch-CPU fp32 forward + Model.inference restatement + SciPy L-BFGS-B'}
     # ---------------------------------------------------------------- stage regime (planted cuboids on oracle logits)
     lg = [l.numpy().copy() for l in logits_ref]
     truth = plant_cuboids(lg[0], lg[1:], K, planted, np.random.Generator(np.random.PCG64(2)))
@@ -244,6 +283,7 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     xs, fs = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy()
     st = {'objects': 0, 'index_mismatches': 0, 'kept_ref': 0, 'kept_dev': 0, 'keep_decision_mismatches': 0, 'box_linf': 0.0,
           'vert_linf_px': 0.0}
+    st_boxd = []
     for b in range(k):
         nr = 0 if dets_p[0][b] is None else len(dets_p[0][b])
         if nr:
@@ -263,7 +303,10 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
         st['keep_decision_mismatches'] += int((kr != kd).sum())
         both = kr & kd
         if both.any():
-            st['box_linf'] = max(st['box_linf'], float(angle_diff(box_params(xs[sl][both]), box_params(raw['x'][both])).max()))
+            dv = angle_diff(box_params(xs[sl][both]), box_params(raw['x'][both]))
+            st_boxd.extend(list(dv))
+            st['box_linf'] = max(st['box_linf'], float(dv.max()))
+    st['boxes'] = _box_stats(st_boxd)
     out['stage'] = st
     # ---------------------------------------------------------------- end to end (fp16 network on the device)
     def match_e2e(det, boxes, dets_o, raws, only_cells=None):
@@ -272,7 +315,7 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
         xs, fs = boxes.x.cpu().numpy(), boxes.fun.cpu().numpy()
         e = {'ref_detections': 0, 'dev_detections': int(n_dev[:k].sum()), 'matched': 0, 'missed': 0, 'vert_linf_px': 0.0,
              'score_linf': 0.0, 'kept_ref': 0, 'kept_dev': 0, 'kept_both': 0, 'box_linf': None, 'fun_rel_median': None}
-        frel, boxd = [], []
+        frel, boxd, vd = [], [], []
         for b in range(k):
             nd = int(n_dev[b])
             sl = slice(b * tk, b * tk + nd)
@@ -296,23 +339,25 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
                     continue
                 e['matched'] += 1
                 e['kept_dev'] += int(fs[sl][j] < 0.1)
-                e['vert_linf_px'] = max(e['vert_linf_px'], float(np.abs(vv[j] - dets_o[3][b][i].numpy()).max()))
+                vd.append(float(np.abs(vv[j] - dets_o[3][b][i].numpy()).max()))
                 e['score_linf'] = max(e['score_linf'], abs(float(sc[j]) - float(dets_o[1][b][i])))
                 frel.append(abs(fs[sl][j] / raw['fun'][i] - 1.0))
                 if raw['kept'][i] and fs[sl][j] < 0.1:
                     e['kept_both'] += 1
-                    dv = angle_diff(box_params(xs[sl][j:j + 1]), box_params(raw['x'][i:i + 1]))[0]
-                    boxd.append(dv)
-                    d = float(dv.max())
-                    e['box_linf'] = d if e['box_linf'] is None else max(e['box_linf'], d)
+                    boxd.append(angle_diff(box_params(xs[sl][j:j + 1]), box_params(raw['x'][i:i + 1]))[0])
+        if vd:
+            e['vert_linf_px'] = max(vd)
+            e['vert_px'] = {kk: vv_ for kk, vv_ in _dist(vd, 0.25).items()}
         if frel:
             e['fun_rel_median'] = float(np.median(frel))
         if boxd:
             # the fit is ill-conditioned for distant boxes (a 0.03 px vertex error moves a box at 50 m by centimetres): the
-            # maximum is one object's; median and per-parameter maxima [Ry, h, w, l, X, Y, Z] say how typical it is
+            # maximum is one object's; the distribution and the per-parameter columns [Ry, h, w, l, X, Y, Z] say how typical it is
             bd = np.stack(boxd)
+            e['box_linf'] = float(bd.max())
             e['box_median'] = float(np.median(bd.max(1)))
             e['box_linf_per_param'] = [float(v) for v in bd.max(0)]
+            e['boxes'] = _box_stats(boxd)
         return e
 
     # (a) the workload's natural detections
@@ -334,7 +379,7 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     out['e2e_planted'] = e_pl
     # (c) the same two comparisons with the network in the fp32 VERIFICATION mode (Model.forward_logits_fp32: the same plan
     # on fp32 tensors, rtm3d_amd/verify.py) and the product's own decode kernels: what is left is fp32 round-off plus the
-    # reference solver's own sensitivity to it (profiles/r02_solver_sensitivity.txt)
+    # reference solver's own sensitivity to it
     lg32 = model.forward_logits_fp32(x_dev[:k])
     det3 = model.decode2d(lg32)
     boxes3 = decode3d_slots(det3, Kd, dim_ref, [0, -0.5, 20])
@@ -347,18 +392,48 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=12):
     out['e2e_fp32_mode_planted'] = match_e2e(det4, boxes4, dets_p, raws_p, only)
     out['e2e_fp32_mode']['logit_linf_rel'] = max(float((a[:k].cpu() - b_).abs().max() / max(1.0, float(b_.abs().max())))
                                                  for a, b_ in zip(lg32, logits_ref))
-    # the names VERDICT r01 asked for, flat
+    # (d) the reference's own sensitivity at the vertex error each mode was measured at (uniform noise of that amplitude on
+    # every vertex coordinate of the planted images' detections, `draws` draws; boxes compared on the planted objects the
+    # reference keeps in both runs)
+    rng = np.random.default_rng(7)
+    sens = {}
+    for mode, e_ in (('fp16', e_pl), ('fp32_mode', out['e2e_fp32_mode_planted'])):
+        eps = float(e_['vert_px']['p50']) if e_.get('vert_px') else 0.0
+        boxd, nit_changed, n_obj = [], 0, 0
+        for _ in range(draws if eps > 0 else 0):
+            for b in range(k):
+                if dets_p[0][b] is None:
+                    continue
+                v = dets_p[3][b].numpy()
+                r2 = solve_ref(dets_p, b, (v + rng.uniform(-eps, eps, v.shape)).astype(np.float32))
+                both = raws_p[b]['kept'] & r2['kept']
+                nit_changed += int((r2['nit'] != raws_p[b]['nit'])[both].sum()); n_obj += int(both.sum())
+                if both.any():
+                    boxd.extend(list(angle_diff(box_params(r2['x'][both]), box_params(raws_p[b]['x'][both]))))
+        sens[mode] = {'eps_px': eps, 'draws': draws, 'solves': n_obj, 'iteration_count_changed': nit_changed, 'boxes': _box_stats(boxd)}
+    out['reference_sensitivity'] = sens
+    # flat summary (the names VERDICT r01 / r02 asked for)
+    bs16, bs32 = e_pl.get('boxes'), out['e2e_fp32_mode_planted'].get('boxes')
     out.update({'stage_box_linf': st['box_linf'], 'e2e_vert_linf_px': max(e_nat['vert_linf_px'], e_pl['vert_linf_px']),
                 'e2e_box_linf': e_pl['box_linf'], 'matched': e_nat['matched'] + e_pl['matched'], 'missed': e_nat['missed'] + e_pl['missed'],
+                'reference_kept_boxes_compared': e_pl['kept_both'],
+                'e2e_box_fp16': bs16['box_linf'] if bs16 else None,
+                'e2e_box_fp32_mode': bs32['box_linf'] if bs32 else None,
+                'reference_sensitivity_at_fp16_vertex_error': sens['fp16']['boxes']['box_linf'] if sens['fp16']['boxes'] else None,
+                'reference_sensitivity_at_fp32_vertex_error': sens['fp32_mode']['boxes']['box_linf'] if sens['fp32_mode']['boxes'] else None,
                 'e2e_box_linf_fp32_mode': out['e2e_fp32_mode_planted']['box_linf'],
-                'e2e_box_median_fp32_mode': out['e2e_fp32_mode_planted'].get('box_median')})
+                'e2e_box_median_fp32_mode': out['e2e_fp32_mode_planted'].get('box_median'),
+                'seconds': None})
     out['note'] = ('stage: device decode kernels on the oracle fp32 logits of the benchmark images with %d exact cuboid projections '
                    'planted per image (bar: identical indices, boxes 1e-4).  e2e: fp16 network on the device vs the fp32 oracle end to '
                    'end, detections matched by (class, y, x); the synthetic-weight workload itself has no cuboid-consistent key points '
-                   '(the reference keeps none), so box L-inf is measured on the same planted cuboids carried through the network '
+                   '(the reference keeps none), so box |d| is measured on the same planted cuboids carried through the network '
                    'additively (device logits + oracle(planted - natural)): planted vertices on the device = exact + real fp16 error.  '
                    'e2e_fp32_mode*: the same comparisons with the network in the fp32 verification mode (same plan, fp32 tensors, '
-                   'fp64 accumulation; product decode kernels)' % planted)
+                   'fp64 accumulation; product decode kernels).  reference_sensitivity: the oracle re-run on its own detections with the '
+                   'vertices moved by uniform noise of each mode\'s median vertex error; per-box L-inf over [Ry, h, w, l, X, Y, Z] in '
+                   'rad / m' % planted)
+    out['seconds'] = round(time.perf_counter() - t_start, 1)
     return out
 
 
@@ -491,6 +566,8 @@ def main():
     if args.heat_bias is not None:
         hb = args.heat_bias
     sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb)
+    if args.zero_weights:
+        sd = type(sd)((kk, vv if kk.endswith(('running_var', 'num_batches_tracked')) else torch.zeros_like(vv)) for kk, vv in sd.items())
     model = rtm3d_amd.create_model(cfg).to(dev).eval()
     model.load_state_dict(sd)
     if args.graph:
@@ -604,6 +681,23 @@ def main():
         if bb_ms > 0:
             roof['backbone_ms'] = bb_ms
             roof['backbone_frac'] = bb_fl / (bb_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS
+        # the three stages of the forward (per-op hipEvent pass): MFMA fraction of each stage's conv FLOPs, and for the ops that
+        # carry no FLOPs (pools, spatial softmax) or whose bytes / time exceeds their flops / time relative to the peaks, HBM
+        stages = {}
+        for nm, pred in (('backbone', lambda n: n.startswith('backbone')),
+                         ('neck', lambda n: n.startswith(('kfpn', 'fusion'))),
+                         ('heads', lambda n: n.startswith('heads'))):
+            ops = [i for i in info if pred(i['name'])]
+            ms = sum(i['ms'] for i in ops)
+            if ms <= 0:
+                continue
+            fl, by = sum(i['flops'] for i in ops), sum(i['bytes'] for i in ops)
+            mf, hb = fl / (ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            hbm_ms = sum(i['ms'] for i in ops if i['ms'] > 0 and i['bytes'] / PEAK_HBM_GBS / 1e9 > i['flops'] / PEAK_FP16_MFMA_TFLOPS / 1e12)
+            stages[nm] = {'ms': round(ms, 4), 'launches': len(ops), 'gflop': round(fl / 1e9, 1), 'frac': round(mf, 4), 'bound': 'mfma',
+                          'algorithmic_gb': round(by / 1e9, 3), 'hbm_frac': round(hb, 4),
+                          'ms_in_hbm_bound_ops': round(hbm_ms, 4)}
+        roof['per_stage'] = stages
         out = {'metric': 'images_per_sec', 'value': total_images / dt, 'unit': 'images/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp16', 'data': 'synthetic',
@@ -622,6 +716,8 @@ def main():
             out['config']['input'] = ('B uint8 360x1240x3 images in HBM -> Resize(1280, bilinear) + letterbox + normalise on the device (rtm3d_preprocess_batch, fp16 NHWC4 output) in every step'
                                       if args.from_uint8 == 'step' else 'the same uint8 images preprocessed ONCE outside the timed region into the fp32 NCHW batch fed in every step')
             out['NOTE'] = 'row n1 measurement, not the BASELINE line (whose input is the normalised fp32 batch)'
+        if args.zero_weights:
+            out['DIAGNOSTIC'] = 'all-zero weights: every activation is zero (not the benchmark workload)'
         if args.graph:
             out['DIAGNOSTIC_graph'] = 'hipGraph replay; roofline.launch_ms from the per-op pass, not from the timed region'
         if args.heat_bias is not None:
