@@ -45,31 +45,53 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
     const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
     const int y0 = ty * SF_TH, x0 = tx * SF_TW;
 
+    // Tile-uniform edge flags: only tiles that touch the image border pay for the per-pixel inside / outside tests (the
+    // 7x7's zero padding, the zero rows / columns the next layer must see); for the ~87 % interior tiles of a 384 x 1280
+    // image they are scalar branches not taken.  (Round 3: the kernel was bound by vector-instruction issue - ~1300 VALU
+    // instructions per wave and tile against 138 MFMAs per SIMD - so the per-pixel index divisions, bounds tests, bias
+    // adds and tap-offset arithmetic went: rows per wave and one lane per column in stage 1, biases as the accumulators'
+    // initial values, tap offsets computed once per lane.)
+    const bool x_edge = (y0 - XO < 0) | (y0 - XO + XH > a.H) | (x0 - XO < 0) | (x0 - XO + XW > a.W);
+    const bool b_edge = (y0 - BO < 0) | (y0 - BO + BH > a.H) | (x0 - BO < 0) | (x0 - BO + BW > a.W);
+
     // ---- 1. image window: straight from the caller's fp32 NCHW batch (a.x_nchw: the NHWC4 conversion pass and its
     // tensor are skipped; pixels outside the image are the 7x7's zero padding), or from the padded NHWC4 fp16 tensor
     // (filled by rtm3d_preprocess_batch).  In the latter, rows above the padded tensor (first tile row of image 0 in the
     // three-layer form) are clamped to its first row - a zero border row, and every base pixel that would use them lies
-    // outside the image anyway.
-    if (a.x_nchw) {
-        const size_t plane = (size_t)a.H * a.W;
-        const float* img = a.x_nchw + (size_t)n * 3 * plane;
-        for (int p = tid; p < XH * XW; p += 256) {
-            const int r = p / XW, c = p - r * XW;
-            const int gy = y0 - XO + r, gx = x0 - XO + c;
-            f16x4 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const float* q = img + (size_t)gy * a.W + gx;
-                v = (f16x4){(f16)q[0], (f16)q[plane], (f16)q[2 * plane], (f16)0.f};
+    // outside the image anyway.  Wave w takes window rows w, w + 4, ...; lane = window column (XW <= 64).
+    static_assert(XW <= 64, "one lane per window column");
+    {
+        constexpr int NR = (XH + 3) / 4;
+        const int gx = x0 - XO + lane;
+        if (a.x_nchw) {
+            const size_t plane = (size_t)a.H * a.W;
+            const float* img = a.x_nchw + (size_t)n * 3 * plane + gx;
+            const bool colok = lane < XW && (!x_edge || (gx >= 0 && gx < a.W));
+            float v[NR][3];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + 4 * i, gy = y0 - XO + r;               // wave-uniform
+                const bool ok = colok && r < XH && (!x_edge || (gy >= 0 && gy < a.H));
+                v[i][0] = v[i][1] = v[i][2] = 0.f;
+                if (ok) {
+                    const float* q = img + (size_t)gy * a.W;
+                    v[i][0] = q[0]; v[i][1] = q[plane]; v[i][2] = q[2 * plane];
+                }
             }
-            *(f16x4*)(xt + p * 4) = v;
-        }
-    } else {
-        const f16* img = a.x4 + (size_t)n * a.x_Hp * a.x_Wp * 4;
-        for (int p = tid; p < XH * XW; p += 256) {
-            const int r = p / XW, c = p - r * XW;
-            int pr = y0 - XO + r + a.x_P;
-            pr = pr > 0 ? pr : 0;
-            *(f16x4*)(xt + p * 4) = *(const f16x4*)(img + ((ptrdiff_t)pr * a.x_Wp + (x0 - XO + c + a.x_P)) * 4);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + 4 * i;
+                if (r < XH && lane < XW) *(f16x4*)(xt + (r * XW + lane) * 4) = (f16x4){(f16)v[i][0], (f16)v[i][1], (f16)v[i][2], (f16)0.f};
+            }
+        } else {
+            const f16* img = a.x4 + (size_t)n * a.x_Hp * a.x_Wp * 4 + (ptrdiff_t)(gx + a.x_P) * 4;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + 4 * i;
+                int pr = y0 - XO + r + a.x_P;
+                pr = pr > 0 ? pr : 0;
+                if (r < XH && lane < XW) *(f16x4*)(xt + (r * XW + lane) * 4) = *(const f16x4*)(img + (ptrdiff_t)pr * a.x_Wp * 4);
+            }
         }
     }
     f16x8 wb[7], wl[5];
@@ -80,13 +102,13 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
     const f32x4 bb = *(const f32x4*)(a.b_base + fk * 4), bl = *(const f32x4*)(a.b_l0 + fk * 4);
     __syncthreads();
 
-    // ---- 2. base_layer on the BH x BW halo
+    // ---- 2. base_layer on the BH x BW halo (accumulators start at the bias)
     auto base_store = [&](const f32x4& acc, int r, int c) {
-        const int gy = y0 - BO + r, gx = x0 - BO + c;
-        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        f16x4 h = {(f16)fmaxf(acc[0] + bb[0], 0.f), (f16)fmaxf(acc[1] + bb[1], 0.f), (f16)fmaxf(acc[2] + bb[2], 0.f),
-                   (f16)fmaxf(acc[3] + bb[3], 0.f)};
-        if (!inside) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        f16x4 h = {(f16)fmaxf(acc[0], 0.f), (f16)fmaxf(acc[1], 0.f), (f16)fmaxf(acc[2], 0.f), (f16)fmaxf(acc[3], 0.f)};
+        if (b_edge) {
+            const int gy = y0 - BO + r, gx = x0 - BO + c;
+            if (!(gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        }
         *(f16x4*)(bt + (r * BW + c) * 16 + fk * 4) = h;
     };
     auto window16 = [&](int r, int c) -> f16x8 {           // window pixels (r, c + 2fk), (r, c + 2fk + 1): 16 bytes, 8-byte aligned
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             if (i < nrows) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = bb;
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky], win[(i + ky) % 7], acc, 0, 0, 0);
                 if (i + 1 < nrows) win[i % 7] = window16(rbase + i + 7, c);     // filter row 6 of the next output row
@@ -119,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
             int q = wave * 16 + frow;
             q = q < RPIX ? q : RPIX - 1;                     // the spare lanes of the last fragment redo its last pixel
             const int r = q / RC, cc = 32 + (q - r * RC);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = bb;
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ky], window16(r + ky, cc), acc, 0, 0, 0);
             base_store(acc, r, cc);
@@ -127,28 +149,38 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
     }
     __syncthreads();
 
+    // K-step s of the two 3x3 layers = taps 2s, 2s + 1 (lane group fk >> 1 picks one) x 16 channels (k half fk & 1);
+    // the 10th tap has zero weights, any valid address will do.  Tap offsets in halves, per lane, once.
+    int tap_y[5], tap_x[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int t = 2 * s + (fk >> 1);
+        t = t < 9 ? t : 8;
+        tap_y[s] = t / 3; tap_x[s] = t - tap_y[s] * 3;
+    }
+
     // ---- 3. level0 on the L0H x L0W map: pixel q -> row q / L0W, column q % L0W (fragments of 16 consecutive pixels)
     {
         constexpr int PIX = L0H * L0W, FR = (PIX + 15) / 16;
+        int toff[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) toff[s] = (tap_y[s] * BW + tap_x[s]) * 16 + (fk & 1) * 8;
+        const bool tl_edge = L1 && ((y0 == 0) | (x0 == 0));
         for (int f = wave; f < FR; f += 4) {
             int q = f * 16 + frow;
             const bool live = q < PIX;
             q = live ? q : PIX - 1;
             const int row = q / L0W, col = q - row * L0W;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f16* bp = bt + (row * BW + col) * 16;
+            f32x4 acc = bl;
 #pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                int t = 2 * s + (fk >> 1);
-                t = t < 9 ? t : 8;                          // the 10th tap has zero weights; any valid address will do
-                const int dy = t / 3, dx = t - dy * 3;
-                const f16x8 xf = *(const f16x8*)(bt + ((row + dy) * BW + col + dx) * 16 + (fk & 1) * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xf, acc, 0, 0, 0);
-            }
-            f16x4 h = {(f16)fmaxf(acc[0] + bl[0], 0.f), (f16)fmaxf(acc[1] + bl[1], 0.f), (f16)fmaxf(acc[2] + bl[2], 0.f),
-                       (f16)fmaxf(acc[3] + bl[3], 0.f)};
+            for (int s = 0; s < 5; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], *(const f16x8*)(bp + toff[s]), acc, 0, 0, 0);
+            f16x4 h = {(f16)fmaxf(acc[0], 0.f), (f16)fmaxf(acc[1], 0.f), (f16)fmaxf(acc[2], 0.f), (f16)fmaxf(acc[3], 0.f)};
             if (L1) {
-                const int gy = y0 - L1 + row, gx = x0 - L1 + col;
-                if (gy < 0 || gx < 0) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};   // level1's zero padding (top / left only)
+                if (tl_edge) {
+                    const int gy = y0 - L1 + row, gx = x0 - L1 + col;
+                    if (gy < 0 || gx < 0) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};   // level1's zero padding (top / left only)
+                }
                 if (live) *(f16x4*)(l0t + q * 16 + fk * 4) = h;
             } else {
                 f16* op = a.out + ((size_t)(n * a.o_Hp + y0 + row + a.o_P) * a.o_Wp + x0 + col + a.o_P) * a.o_C + a.o_coff + fk * 4;
@@ -171,24 +203,24 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
 #pragma unroll
         for (int c = 0; c < 2; ++c) b1[c] = *(const f32x4*)(a.b_l1 + c * 16 + fk * 4);
         const int so = (fk & 1) * 16 + (fk >> 1) * 8;
+        int t1off[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) t1off[s] = (tap_y[s] * L0W + tap_x[s] + 2 * frow) * 16 + (fk & 1) * 8;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int oy = wave * 2 + j;
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const f16* lp = l0t + (2 * oy * L0W) * 16;
+            f32x4 acc[2] = {b1[0], b1[1]};
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                int t = 2 * s + (fk >> 1);
-                t = t < 9 ? t : 8;
-                const int dy = t / 3, dx = t - dy * 3;
-                const f16x8 xf = *(const f16x8*)(l0t + ((2 * oy + dy) * L0W + 2 * frow + dx) * 16 + (fk & 1) * 8);
+                const f16x8 xf = *(const f16x8*)(lp + t1off[s]);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[c][s], xf, acc[c], 0, 0, 0);
             }
             uint32_t u[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const f16x4 h = {(f16)fmaxf(acc[c][0] + b1[c][0], 0.f), (f16)fmaxf(acc[c][1] + b1[c][1], 0.f),
-                                 (f16)fmaxf(acc[c][2] + b1[c][2], 0.f), (f16)fmaxf(acc[c][3] + b1[c][3], 0.f)};
+                const f16x4 h = {(f16)fmaxf(acc[c][0], 0.f), (f16)fmaxf(acc[c][1], 0.f), (f16)fmaxf(acc[c][2], 0.f), (f16)fmaxf(acc[c][3], 0.f)};
                 __builtin_memcpy(u[c], &h, 8);
             }
             // rows (16-lane groups) 1,3 of the c = 0 registers <-> rows 0,2 of the c = 1 registers: 8 consecutive channels per lane
