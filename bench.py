@@ -64,6 +64,7 @@ def parse_args():
                          'normalise on the device (two launches, straight into the fp16 input tensor) in front of the plan; once: the same images are '
                          'preprocessed once, outside the timed region, into the fp32 NCHW batch that is then fed like the BASELINE line (the A/B partner)')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
+    ap.add_argument('--sparse-heads', action='store_true', help='DIAGNOSTIC (not the BASELINE line): the detect3d call surface with the regression head branches evaluated at the detected peaks only (Model.decode2d_sparse); Model.forward() and the headline keep all four dense maps')
     ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
@@ -579,7 +580,7 @@ def main():
 
     from rtm3d_amd.pipeline import Detect3DPipeline
     pipe = Detect3DPipeline(model, B, dev, gather='always' if use_dist else True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus,
-                            depth=args.depth or None, side_streams=args.side_streams or None) if not args.serial else None
+                            depth=args.depth or None, side_streams=args.side_streams or None, sparse_heads=args.sparse_heads) if not args.serial else None
     if pipe is not None and use_dist:
         pipe.time_gather = True                 # event pair around the collective on the side stream (diagnostics)
 
@@ -605,18 +606,24 @@ def main():
         if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
             i = pipe.submit(x, K)
             return i, pipe.det[i % pipe.depth]
-        det, boxes, _ = model.detect3d(x, K)
+        det, boxes, _ = model.detect3d(x, K, sparse_heads=args.sparse_heads)
         rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, topk, boxes)
         return rdist.all_gather_records(rec, always=use_dist), det
 
     # ---- warm-up (also records the plan) and choice of the dominant kernel for the live probe
     rec, det = step()
     torch.cuda.synchronize(dev)
-    plan = model._plan_for(B, H, W, dev)
-    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in (3, 16, 2, 2)]
+    plan = model._plan_for(B, H, W, dev, 'peaks' if args.sparse_heads else 'dense')
+    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in ((3,) if args.sparse_heads else (3, 16, 2, 2))]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
-    info = plan.forward_timed(stream, x.data_ptr(), [o.data_ptr() for o in outs])
+    optrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
+    plan.forward_timed(stream, x.data_ptr(), optrs)
+    info = plan.forward_timed(stream, x.data_ptr(), optrs)
+    peak_info = None
+    if args.sparse_heads:
+        pk = [t.data_ptr() for t in plan.peak_out] + [0, 0]
+        plan.peak.forward_timed(stream, 0, pk)
+        peak_info = plan.peak.forward_timed(stream, 0, pk)
     dom = max(range(len(info)), key=lambda i: info[i]['ms'])
     if not args.graph:
         plan.probe_set(dom)
@@ -716,6 +723,13 @@ def main():
             out['config']['input'] = ('B uint8 360x1240x3 images in HBM -> Resize(1280, bilinear) + letterbox + normalise on the device (rtm3d_preprocess_batch, fp16 NHWC4 output) in every step'
                                       if args.from_uint8 == 'step' else 'the same uint8 images preprocessed ONCE outside the timed region into the fp32 NCHW batch fed in every step')
             out['NOTE'] = 'row n1 measurement, not the BASELINE line (whose input is the normalised fp32 batch)'
+        if args.sparse_heads:
+            out['DIAGNOSTIC_sparse_heads'] = ('detect3d call surface with peaks-only regression heads: heat map dense, offset_fr_main / main_offset at the '
+                                              '<= %d peaks per image through a patch plan (not the BASELINE line: Model.forward() returns four dense maps)' % topk)
+            out['config']['gflop_per_image_dense_part'] = flops_fwd / B / 1e9
+            out['sparse_heads'] = {'patch_plan_ms': round(sum(i['ms'] for i in peak_info), 4),
+                                   'patch_plan_gflop_per_batch': round(sum(i['flops'] for i in peak_info) / 1e9, 1),
+                                   'ops': [{'name': i['name'], 'kernel': i['kernel'], 'ms': round(i['ms'], 4)} for i in peak_info]}
         if args.zero_weights:
             out['DIAGNOSTIC'] = 'all-zero weights: every activation is zero (not the benchmark workload)'
         if args.graph:
@@ -733,7 +747,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(bb, sd, H, W, cfg, full=args.cpu_full, threads=args.cpu_threads)
         else:
             out['cpu_baseline'] = None
-        if not args.no_parity and world == 1 and not args.from_uint8:
+        if not args.no_parity and world == 1 and not args.from_uint8 and not args.sparse_heads:
             out['parity'] = parity_check(model, cfg, sd, bb, x, args.parity_images, dev)
         else:
             out['parity'] = None

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 5
+#define RTM3D_ABI_VERSION 6
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -57,6 +57,11 @@ int rtm3d_tensor_upload(rtm3d_ctx* ctx, int id, int c0, int C, const float* h_nc
 
 /* Device blob (packed weights / folded biases).  Copies `bytes` from host; returns blob id.      */
 int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t bytes, int* id);
+/* Device address and geometry of a plan tensor / device address of a blob: for kernels that fill or read plan storage from
+ * outside the replay (rtm3d_gather_peak_patches writes the patch plan's input tensor and its (y, x) blob).  Any output
+ * pointer of rtm3d_tensor_info may be NULL.  d_base = padded element [0][0][0][0] (NHWC fp16, border `border`).         */
+int rtm3d_tensor_info(rtm3d_ctx* ctx, int id, void** d_base, int* B, int* H, int* W, int* C, int* border);
+int rtm3d_blob_address(rtm3d_ctx* ctx, int id, void** d_ptr, size_t* bytes);
 
 /* Copy the caller's fp32 NCHW (B,3,H,W) image into a 4-channel padded NHWC fp16 tensor (4th channel
  * zero, border >= 4): operand layout of the register-direct MFMA stem (kernel = 3 with cin = 4).      */
@@ -120,6 +125,11 @@ int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv
  * "smoke" head table), outputs = rtm3d_forward's first nheads fp32 NCHW logit buffers, cout4[i] channels.  Weights: fp16 [head][tap][8 k-blocks][64 lanes][8]
  * (MFMA fragment order, 16 zero-padded rows per head), bias fp32 [head][16].                          */
 int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4);
+/* Patch plans (peaks-only regression heads, csrc/sparse_heads.hip): `tensor` holds one S x S window per "image" (= detection
+ * slot, no border); window position (i, j) of slot s lies at map pixel (y_s + i - origin, x_s + j - origin) with (y_s, x_s)
+ * from `yx_blob` ([slots][2] int32, -1 = empty slot; written per batch by rtm3d_gather_peak_patches).  Positions outside
+ * the img_H x img_W map are zeroed: they are the zero padding of the next convolution (models/nets/header.py:24-37).  */
+int rtm3d_op_patch_mask(rtm3d_ctx* ctx, int tensor, int yx_blob, int img_H, int img_W, int origin);
 
 /* Max pooling k x k / stride / pad over channel slice, NHWC fp16 (models/nets/dla.py:170-172,
  * models/nets/resnet.py:128).  Inputs are post-ReLU (>= 0) so the zero border equals -inf padding. */
@@ -173,6 +183,19 @@ int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_f
                    const float* d_main_offset, int B, int ncls, int H, int W, float score_thresh,
                    int topk, float down_sample, void* d_workspace, int32_t* d_n, int64_t* d_cls,
                    float* d_score, float* d_mproj, float* d_verts, float* d_bbox);
+
+/* Peaks-only regression heads: what Model.inference reads of the regression maps is their value at the <= topk peaks
+ * (models/model.py:47-50,124-128: offset_fr_main and main_offset through two gathers; vertex_offset is never read).
+ * rtm3d_gather_peak_patches: after rtm3d_decode2d in its peaks-only mode, copy for every live slot the samples of the fused
+ * map z (padded NHWC fp16, 256 channels, border z_pad) that the three head convolutions of a peak depend on into a
+ * 15 x 15 x 256 patch (layout: csrc/sparse_heads.hip) and the peak's (y, x) into d_yx; empty slots get (-1, -1).
+ * rtm3d_decode2d_finish: sub-pixel key point, 8 vertices and the 2D box of every live slot from the regression logits
+ * evaluated at its peak ([B*topk][16] and [B*topk][2] fp32) - the second half of rtm3d_decode2d, same fp32 operation order;
+ * d_mproj holds the integer key points on entry and the sub-pixel ones (x down_sample) on return.                      */
+int rtm3d_gather_peak_patches(void* stream, const void* d_z, int z_H, int z_W, int z_C, int z_pad, int B, int topk,
+                              const int32_t* d_n, const float* d_peak_xy, void* d_patch, int32_t* d_yx);
+int rtm3d_decode2d_finish(void* stream, int B, int topk, const int32_t* d_n, const float* d_reg_offset_fr_main,
+                          const float* d_reg_main_offset, float down_sample, float* d_mproj, float* d_verts, float* d_bbox);
 
 /* ------------------------------------------------------------------ 3D decode
  * Per object: minimise the 8-corner reprojection error over [sin,cos,l,h,w,X,Y,Z] with an fp64

@@ -131,7 +131,14 @@ struct Conv32S2Args {
     int op_Hp, op_Wp, op_C, op_P, op_coff;
 };
 
+struct PatchMaskArgs {
+    f16* base;              // [n_slots][S][S][C] patch tensor (no border)
+    const int32_t* yx;      // [n_slots][2] peak (y, x) in map pixels, -1 = empty slot (written by rtm3d_gather_peak_patches)
+    int n_slots, S, C, img_H, img_W, origin;
+};
+
 // kernel launchers (each returns hipGetLastError())
+hipError_t launch_patch_mask(const PatchMaskArgs& a, hipStream_t s);
 hipError_t launch_conv32s2_fused(const Conv32S2Args& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_stem_fused(const StemFusedArgs& a, hipStream_t s);
 hipError_t launch_conv_headout(const HeadOutArgs& a, hipStream_t s);

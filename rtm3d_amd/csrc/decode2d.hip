@@ -245,6 +245,51 @@ extern "C" int rtm3d_decode2d(void* stream, const float* d_main_kf, const float*
     return 0;
 }
 
+// Second half of the 2D decode for the peaks-only regression heads (sparse_heads.hip): rtm3d_decode2d ran in its peaks-only
+// mode (class, score, integer key point per slot); the regression logits of every slot - [B*topk][16] offset_fr_main and
+// [B*topk][2] main_offset, evaluated at the peak - arrive here.  Same fp32 operation order as decode2d_kernel, incl. the
+// position-dependent ATen sigmoid of the contiguous (2, N) gather.
+__global__ __launch_bounds__(256) void decode2d_finish_kernel(int B, int topk, const int32_t* __restrict__ n_per_image,
+                                                              const float* __restrict__ reg_offs, const float* __restrict__ reg_moff,
+                                                              float down, float* __restrict__ mproj, float* __restrict__ verts,
+                                                              float* __restrict__ bbox) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * topk) return;
+    const int b = i / topk, rank = i - b * topk, nsel = n_per_image[b];
+    if (rank >= nsel) return;
+    const float x = mproj[(size_t)i * 2], y = mproj[(size_t)i * 2 + 1];          // integer peak, as the peaks-only decode left it
+    const int n2 = 2 * nsel;
+    const int vend = (n2 / ATEN_VSTEP) * ATEN_VSTEP;
+    const float sx = sigmoid_aten(reg_moff[(size_t)i * 2], rank < vend);
+    const float sy = sigmoid_aten(reg_moff[(size_t)i * 2 + 1], (nsel + rank) < vend);
+    const float xf = x + sx, yf = y + sy;
+    mproj[(size_t)i * 2] = down * xf;
+    mproj[(size_t)i * 2 + 1] = down * yf;
+    const float* of = reg_offs + (size_t)i * 16;
+    float minx = INFINITY, miny = INFINITY, maxx = -INFINITY, maxy = -INFINITY;
+    for (int k = 0; k < 8; ++k) {
+        const float vx = down * (of[2 * k] + xf);
+        const float vy = down * (of[2 * k + 1] + yf);
+        verts[(size_t)i * 16 + 2 * k] = vx;
+        verts[(size_t)i * 16 + 2 * k + 1] = vy;
+        minx = fminf(minx, vx); miny = fminf(miny, vy);
+        maxx = fmaxf(maxx, vx); maxy = fmaxf(maxy, vy);
+    }
+    bbox[(size_t)i * 4 + 0] = minx; bbox[(size_t)i * 4 + 1] = miny;
+    bbox[(size_t)i * 4 + 2] = maxx; bbox[(size_t)i * 4 + 3] = maxy;
+}
+
+extern "C" int rtm3d_decode2d_finish(void* stream, int B, int topk, const int32_t* d_n, const float* d_reg_offset_fr_main,
+                                     const float* d_reg_main_offset, float down_sample, float* d_mproj, float* d_verts, float* d_bbox) {
+    if (B <= 0 || topk <= 0) { rt_set_error("decode2d_finish: bad sizes"); return 1; }
+    if (!d_n || !d_reg_offset_fr_main || !d_reg_main_offset || !d_mproj || !d_verts || !d_bbox) { rt_set_error("decode2d_finish: null pointer"); return 1; }
+    hipLaunchKernelGGL(decode2d_finish_kernel, dim3((B * topk + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, topk, d_n,
+                       d_reg_offset_fr_main, d_reg_main_offset, down_sample, d_mproj, d_verts, d_bbox);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rt_set_error("decode2d_finish launch: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // "smoke" head-table variant.  The branch's source is not part of the
 // reference snapshot, so this decode follows the published SMOKE formulation (Liu et al. 2020) and its

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX, OP_PATCH_MASK };
 
 struct Op {
     OpKind kind;
@@ -42,6 +42,7 @@ struct Op {
     HeadOutArgs ho;
     StemFusedArgs sf;
     Conv32S2Args c32;
+    PatchMaskArgs pm;
 };
 
 struct rtm3d_ctx {
@@ -187,6 +188,26 @@ extern "C" int rtm3d_blob_create(rtm3d_ctx* ctx, const void* h_data, size_t byte
     ctx->blobs.push_back(p);
     ctx->blob_bytes.push_back(bytes);
     *id = (int)ctx->blobs.size() - 1;
+    return 0;
+}
+
+extern "C" int rtm3d_tensor_info(rtm3d_ctx* ctx, int id, void** d_base, int* B, int* H, int* W, int* C, int* border) {
+    Tensor* t = ctx ? get_tensor(ctx, id) : nullptr;
+    if (!t) RT_FAIL("tensor_info: bad tensor %d", id);
+    if (d_base) *d_base = t->base;
+    if (B) *B = t->B;
+    if (H) *H = t->H;
+    if (W) *W = t->W;
+    if (C) *C = t->C;
+    if (border) *border = t->P;
+    return 0;
+}
+
+static void* get_blob(rtm3d_ctx* ctx, int id, size_t* bytes);
+extern "C" int rtm3d_blob_address(rtm3d_ctx* ctx, int id, void** d_ptr, size_t* bytes) {
+    void* p = ctx ? get_blob(ctx, id, bytes) : nullptr;
+    if (!p || !d_ptr) RT_FAIL("blob_address: bad blob %d", id);
+    *d_ptr = p;
     return 0;
 }
 
@@ -465,6 +486,22 @@ extern "C" int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_cof
     return 0;
 }
 
+extern "C" int rtm3d_op_patch_mask(rtm3d_ctx* ctx, int tensor, int yx_blob, int img_H, int img_W, int origin) {
+    Tensor* t = ctx ? get_tensor(ctx, tensor) : nullptr;
+    if (!t) RT_FAIL("op_patch_mask: bad tensor");
+    if (t->P != 0 || t->H != t->W || (t->C % 8) || img_H < 1 || img_W < 1 || origin < 0 || origin >= t->H) RT_FAIL("op_patch_mask: the patch tensor must be square, borderless, with a multiple of 8 channels");
+    size_t bytes = 0;
+    const int32_t* yx = (const int32_t*)get_blob(ctx, yx_blob, &bytes);
+    if (!yx || bytes < (size_t)t->B * 2 * sizeof(int32_t)) RT_FAIL("op_patch_mask: the (y, x) blob needs 2 int32 per slot");
+    Op op;
+    op.kind = OP_PATCH_MASK; op.name = "patch_mask";
+    op.pm.base = t->base; op.pm.yx = yx; op.pm.n_slots = t->B; op.pm.S = t->H; op.pm.C = t->C;
+    op.pm.img_H = img_H; op.pm.img_W = img_W; op.pm.origin = origin;
+    op.flops = 0; op.bytes = 0;
+    ctx->ops.push_back(op);
+    return 0;
+}
+
 extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int bias_blob, int nheads, const int* cout4) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     if (!in || !cout4) RT_FAIL("op_headout: bad arguments");
@@ -601,6 +638,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_MAXPOOL: e = launch_maxpool(op.pool, s); break;
         case OP_SOFTMAX: e = launch_softmax_fuse(op.sm, s); break;
+        case OP_PATCH_MASK: e = launch_patch_mask(op.pm, s); break;
     }
     if (e != hipSuccess) { rt_set_error("launch of op '%s' failed: %s", op.name.c_str(), hipGetErrorString(e)); return 1; }
     return 0;

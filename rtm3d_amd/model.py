@@ -138,8 +138,14 @@ class Model(object):
         return self.forward(x)
 
     # ------------------------------------------------------------------ hot path
-    def _plan_for(self, B, H, W, device):
-        key = (B, H, W, device.index)
+    def _plan_for(self, B, H, W, device, heads='dense'):
+        """heads = 'dense': all branches on the whole map (Model.forward); 'peaks': the heat map alone plus the patch plan that
+        evaluates the regression branches at the detected peaks (detect3d(sparse_heads=True), csrc/sparse_heads.hip)."""
+        if heads not in ('dense', 'peaks'):
+            raise ValueError("heads must be 'dense' or 'peaks'")
+        if heads == 'peaks' and self._head_variant not in (None, 'rtm3d'):
+            raise NotImplementedError('peaks-only regression heads exist for the rtm3d head table')
+        key = (B, H, W, device.index) if heads == 'dense' else (B, H, W, device.index, heads)
         p = self._plans.get(key)
         if p is not None:
             self._plans[key] = self._plans.pop(key)          # most recently used last
@@ -153,12 +159,20 @@ class Model(object):
             if self._wcache is None:
                 self._wcache = WeightCache(self._sd)
             ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache,
-                                     num_classes=self._num_classes)
+                                     num_classes=self._num_classes, dense_heads=1 if heads == 'peaks' else None)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
                 # small batches are bound by launch gaps, not by the kernels: replay those plans as one hipGraph
                 use_graph = self.use_graph if self.use_graph is not None else B <= GRAPH_MAX_BATCH
                 p.set_graph(use_graph)
+                if heads == 'peaks':
+                    topk = int(self.config.DETECTOR.TOPK_CANDIDATES)
+                    pir = plan_mod.build_peak_plan(self._sd, B * topk, (H // 4, W // 4), self._head_variant, cache=self._wcache,
+                                                   num_classes=self._num_classes)
+                    p.peak = plan_mod.RealizedPlan(pir, device.index)
+                    p.peak.set_graph(False)
+                    # the regression logits at the peaks, [slots][16] and [slots][2] fp32 (the patch plan's two outputs)
+                    p.peak_out = [torch.zeros(B * topk, c, 1, 1, dtype=torch.float32, device=device) for c in pir.head_channels]
             self._plans[key] = p
             self._wcache.save()          # no-op unless RTM3D_WEIGHT_CACHE_DIR is set
         return p
@@ -181,14 +195,15 @@ class Model(object):
         dev = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
         return self._plan_for(B, H, W, dev).input_tensor()
 
-    def forward_logits(self, x, preloaded=None, out=None):
+    def forward_logits(self, x, preloaded=None, out=None, heads='dense'):
         """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23).
         preloaded=(B, H, W): ``x`` is None and the plan's input tensor was filled by preprocess_batch(model=self).
         out: where the logits go instead of four fresh tensors - a tuple of contiguous fp32 CUDA tensors of the logit
         shapes, or ``'reuse'`` for one set of buffers owned by the plan of this shape (every such call returns the SAME
         tensors: consume them, in stream order, before the next call).  A hipGraph replay is keyed by these addresses
         (rtm3d_forward), so a loop that holds on to its fresh outputs would pay a capture per call; with out= it replays one
-        graph (the bs=1 detect.py loop)."""
+        graph (the bs=1 detect.py loop).
+        heads='peaks': only the heat-map branch is evaluated (a 1-tuple comes back); feed it to ``decode2d_sparse``."""
         if preloaded is not None:
             if x is not None:
                 raise ValueError('forward_logits: pass x=None with preloaded=(B, H, W)')
@@ -202,9 +217,9 @@ class Model(object):
             B, _, H, W = x.shape
             dev = x.device
             xptr = x.data_ptr()
-        plan = self._plan_for(B, H, W, dev)
+        plan = self._plan_for(B, H, W, dev, heads)
         with torch.cuda.device(dev):
-            shapes = [(B, c, H // 4, W // 4) for c in self._head_channels]
+            shapes = [(B, c, H // 4, W // 4) for c in (self._head_channels if heads == 'dense' else self._head_channels[:1])]
             if out is None:
                 outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
             elif isinstance(out, str):
@@ -255,9 +270,37 @@ class Model(object):
             return pred_logits
         return self.inference(pred_logits), pred_logits
 
-    def decode2d(self, pred_logits, out=None):
-        """Fixed-size device results of the 2D decode (no host sync)."""
-        smoke = self._head_variant == 'smoke'
+    def decode2d_sparse(self, heat_logits, out=None):
+        """2D decode with the regression branches evaluated at the detected peaks only (what Model.inference reads of
+        them: models/model.py:47-50,124-128): peaks from the dense heat map (NMS + top-k, identical to decode2d's), the z
+        samples each peak depends on gathered into patches, the three head convs of branches offset_fr_main / main_offset as a
+        patch plan on the MFMA conv kernels, then the sub-pixel / vertex arithmetic of decode2d.  heat_logits: the 1-tuple of
+        ``forward_logits(x, heads='peaks')`` (its plan still holds the fused map z of that forward: call this next, on the
+        same stream).  Same Detections as decode2d on the dense logits, vertices to fp16 round-off of the network."""
+        hm = heat_logits[0] if isinstance(heat_logits, (tuple, list)) else heat_logits
+        B, _, Hm, Wm = hm.shape
+        dev = hm.device
+        plan = self._plan_for(B, 4 * Hm, 4 * Wm, dev, 'peaks')
+        det = self.decode2d((hm,), out=out, peaks_only=True)
+        lib = _lib.load()
+        topk = det.topk
+        zbase, zB, zH, zW, zC, zP = plan.tensor_info(plan.plan.named['z'])
+        pbase = plan.peak.tensor_info(plan.peak.plan.named['zp'])[0]
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.rtm3d_gather_peak_patches(ctypes.c_void_p(stream), ctypes.c_void_p(zbase), zH, zW, zC, zP, B, topk,
+                                                     det.n.data_ptr(), det.mproj.data_ptr(), ctypes.c_void_p(pbase),
+                                                     ctypes.c_void_p(plan.peak.blob_address(plan.peak.yx_blob))), 'gather_peak_patches')
+            plan.peak.forward(stream, 0, [t.data_ptr() for t in plan.peak_out] + [0, 0])
+            _lib.check(lib.rtm3d_decode2d_finish(ctypes.c_void_p(stream), B, topk, det.n.data_ptr(), plan.peak_out[0].data_ptr(),
+                                                 plan.peak_out[1].data_ptr(), float(self.config.MODEL.DOWN_SAMPLE),
+                                                 det.mproj.data_ptr(), det.verts.data_ptr(), det.bbox.data_ptr()), 'decode2d_finish')
+        return det
+
+    def decode2d(self, pred_logits, out=None, peaks_only=None):
+        """Fixed-size device results of the 2D decode (no host sync).  peaks_only: classes, scores and integer key points
+        alone (default: the 'smoke' head table)."""
+        smoke = self._head_variant == 'smoke' if peaks_only is None else bool(peaks_only)
         used = (pred_logits[0],) if smoke else (pred_logits[0], pred_logits[1], pred_logits[2])
         for t in used:
             if not t.is_cuda:
@@ -331,14 +374,22 @@ class Model(object):
                 'vertex_offset_logits': logits[3]}
 
     # ------------------------------------------------------------------ fused device pipeline
-    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), fp32_verify=False):
+    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), fp32_verify=False, sparse_heads=False):
         """forward + 2D decode + 3D decode, all stream-ordered on the device (no host sync).
         K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D, logits).
         fp32_verify=True: the network runs in the fp32 verification mode (forward_logits_fp32), the decode kernels are the
-        product's own."""
+        product's own.  sparse_heads=True: the detect.py call surface never reads the dense regression maps, so only the heat
+        map is computed densely and the regression branches at the detected peaks (decode2d_sparse); `logits` is then the
+        heat map alone."""
         from .model_utils import decode3d_slots, decode_smoke_slots
-        logits = self.forward_logits_fp32(x) if fp32_verify else self.forward_logits(x)
-        det = self.decode2d(logits)
+        if sparse_heads:
+            if fp32_verify:
+                raise ValueError('detect3d: sparse_heads and fp32_verify are separate modes')
+            logits = self.forward_logits(x, heads='peaks')
+            det = self.decode2d_sparse(logits)
+        else:
+            logits = self.forward_logits_fp32(x) if fp32_verify else self.forward_logits(x)
+            det = self.decode2d(logits)
         dim_ref = dim_ref if dim_ref is not None else self.config.DETECTOR.dim_ref
         if len(dim_ref) < self._num_classes:
             # the reference would raise IndexError at dim_ref[cls] (utils/model_utils.py:293); the kernel only clamps

@@ -32,8 +32,12 @@ SMALL_BATCH = 2      # batches whose 3D decode (a serial fp64 iteration per obje
 
 class Detect3DPipeline(object):
     def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=None, decode3d=True,
-                 side_cus=0, side_streams=None):
+                 side_cus=0, side_streams=None, sparse_heads=False):
         self.model, self.B, self.dev = model, batch, torch.device(device)
+        # sparse_heads: this call surface hands out detection records, never the dense logits, so the regression branches are
+        # evaluated at the detected peaks only (Model.decode2d_sparse); the records agree with the dense path's to fp16 round-off
+        self.sparse_heads = bool(sparse_heads)
+        self.heads = 'peaks' if self.sparse_heads else 'dense' 
         self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
         dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
         if len(dim_ref) < getattr(model, '_num_classes', 0):
@@ -101,7 +105,7 @@ class Detect3DPipeline(object):
 
         def feed():
             preprocess.preprocess_batch(images, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=resize_to, model=self.model)
-            return self.model.forward_logits(None, preloaded=(self.B, H, W), out='reuse')
+            return self.model.forward_logits(None, preloaded=(self.B, H, W), out='reuse', heads=self.heads)
         return self._submit(feed, K_per_image)
 
     def submit(self, x, K_per_image):
@@ -112,7 +116,7 @@ class Detect3DPipeline(object):
             # rtm3d_amd.distributed.padded_shard)
             raise ValueError('Detect3DPipeline was built for batches of %d images, got input of shape %s'
                              % (self.B, tuple(x.shape)))
-        return self._submit(lambda: self.model.forward_logits(x, out='reuse'), K_per_image)
+        return self._submit(lambda: self.model.forward_logits(x, out='reuse', heads=self.heads), K_per_image)
 
     def _submit(self, run_network, K_per_image):
         if not isinstance(K_per_image, torch.Tensor) or K_per_image.numel() != self.B * 9 or not K_per_image.is_cuda:
@@ -123,7 +127,10 @@ class Detect3DPipeline(object):
         if i >= self.depth:
             main.wait_event(self.ev_b[s])                 # slot s is free again
         logits = run_network()
-        self.model.decode2d(logits, out=self.det[s])
+        if self.sparse_heads:
+            self.model.decode2d_sparse(logits, out=self.det[s])
+        else:
+            self.model.decode2d(logits, out=self.det[s])
         self.K_slot[s].copy_(K_per_image.reshape(self.B, 9), non_blocking=True)     # main stream, ordered before A_s
         K_per_image = self.K_slot[s]
         self.ev_a[s].record(main)

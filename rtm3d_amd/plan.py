@@ -142,6 +142,24 @@ class Plan(object):
         self.ops.append({'op': 'headout', 'name': name, 'inp': inp, 'w': [np.asarray(w, np.float32) for w in ws],
                          'bias': [np.asarray(b, np.float32) for b in biases]})
 
+    def conv_taps(self, inps, outs, ws, biases, taps, Hm, Wm, relu=False, name='', out_nchw=0):
+        """Convolution with an explicit tap list and iteration domain (no implied padding): output (y, x), y < Hm, x < Wm, reads
+        input pixels (y + dy, x + dx) for (dy, dx) in taps.  inps / outs / ws / biases: one entry per group (same shapes);
+        ws[g]: (cout, cin, len(taps)).  outs[g] None with out_nchw = k: fp32 NCHW result in output slot k - 1."""
+        G = len(inps)
+        cout, cin, nt = ws[0].shape
+        assert nt == len(taps) and all(i.C == cin for i in inps)
+        wt = np.stack([np.stack([w[:, :, t] for t in range(nt)], 0) for w in ws], 0)             # (G, taps, cout, cin)
+        self.ops.append({'op': 'conv', 'name': name, 'inp': list(inps), 'out': list(outs), 'res': [None] * G, 'Hm': Hm, 'Wm': Wm,
+                         'in_stride': 1, 'out_scale': 1, 'cin': cin, 'cout': cout, 'groups': G, 'taps': [list(taps)] * G,
+                         'out_off': [(0, 0)] * G, 'relu': relu, 'w': wt.astype(np.float32),
+                         'bias': np.stack([np.asarray(b, np.float32) for b in biases], 0), 'out_nchw': out_nchw, 'out_hw': (Hm, Wm)})
+
+    def patch_mask(self, t, origin, name='patch_mask'):
+        """Patch plans (build_peak_plan): zero the window positions of `t` that lie outside the map (they are the next conv's
+        zero padding); position (i, j) of slot s is map pixel (y_s + i - origin, x_s + j - origin)."""
+        self.ops.append({'op': 'patch_mask', 'name': name, 't': t, 'origin': origin})
+
     def softmax_fuse(self, z_in, z_out, us, name=''):
         self.ops.append({'op': 'softmax', 'name': name, 'z_in': z_in, 'z_out': z_out, 'us': list(us)})
 
@@ -284,19 +302,66 @@ def _build_resnet(P, sd, H, W, depth, feat_out):
             inpl = pl
 
 
-def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None, num_classes=3):
-    """state_dict: reference key names -> torch tensors.  H, W multiples of 32.  cache: a WeightCache of this state dict."""
+def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None, num_classes=3, dense_heads=None):
+    """state_dict: reference key names -> torch tensors.  H, W multiples of 32.  cache: a WeightCache of this state dict.
+    dense_heads = k: only the first k head branches are evaluated on the whole map (1 = the heat map alone: the other
+    branches then come from build_peak_plan at the detected peaks)."""
     global _CACHE
     _CACHE = cache
     try:
-        P = _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes)
+        P = _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes, dense_heads)
     finally:
         _CACHE = None
     P.cache = cache
     return P
 
 
-def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3):
+PEAK_PATCH = 15          # 5 x 5 window of the first head conv x its three dilation-6 taps per axis
+
+
+def build_peak_plan(state_dict, slots, map_hw, head_variant='rtm3d', cache=None, num_classes=3):
+    """Patch plan of the peaks-only regression heads (csrc/sparse_heads.hip): one "image" per detection slot.
+      zp  [slots, 15, 15, 256]  gathered samples of the fused map z (rtm3d_gather_peak_patches)
+      h1p [slots, 5, 5, 2*256]  = ReLU(BN(conv3x3 dil 6)) of branches offset_fr_main | main_offset on the 5 x 5 window: on the
+                                  patch layout the dilated conv is a conv with taps {0, 5, 10}^2 and no padding
+      h2p [slots, 3, 3, 2*256]  = ReLU(BN(conv3x3)) on the 3 x 3 window (valid conv of the 5 x 5 one)
+      out [slots, 16] and [slots, 2] fp32 = the two regression logits AT the peak (valid 3x3 conv of the 3 x 3 window)
+    Window positions outside the map are zeroed after each conv: they are the next conv's zero padding (header.py:15-37).
+    map_hw = (H/4, W/4) of the dense heat map."""
+    global _CACHE
+    if head_variant not in (None, 'rtm3d'):
+        raise NotImplementedError('peaks-only regression heads exist for the rtm3d head table')
+    _CACHE = cache
+    try:
+        heads = head_table(head_variant, num_classes)[1:3]          # offset_fr_main (16), main_offset (2); vertex_offset is never read
+        P = Plan(slots, PEAK_PATCH, PEAK_PATCH)
+        P.map_hw = (int(map_hw[0]), int(map_hw[1]))
+        oc, G = 256, len(heads)
+        zp = P.tensor(PEAK_PATCH, PEAK_PATCH, oc, 0, name='zp')
+        h1 = P.tensor(5, 5, G * oc, 0, name='h1p')
+        h2 = P.tensor(3, 3, G * oc, 0, name='h2p')
+        ws, bs = zip(*[fold_bn(state_dict, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in heads])
+        w6 = np.concatenate(ws, 0).reshape(G * oc, oc, 9)
+        P.conv_taps([zp], [h1], [w6], [np.concatenate(bs, 0)], [(5 * ky, 5 * kx) for ky in range(3) for kx in range(3)], 5, 5,
+                    relu=True, name='peaks.conv_d6')
+        P.patch_mask(h1, 2, name='peaks.mask_h1')
+        taps3 = [(ky, kx) for ky in range(3) for kx in range(3)]
+        ws, bs = zip(*[fold_bn(state_dict, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in heads])
+        P.conv_taps([P.sub(h1, g * oc, oc) for g in range(G)], [P.sub(h2, g * oc, oc) for g in range(G)],
+                    [w.reshape(oc, oc, 9) for w in ws], bs, taps3, 3, 3, relu=True, name='peaks.conv_d1')
+        P.patch_mask(h2, 1, name='peaks.mask_h2')
+        for g, (seq, last, c) in enumerate(heads):
+            w, b = fold_bn(state_dict, 'detect_header.%s.%s' % (seq, last))
+            P.conv_taps([P.sub(h2, g * oc, oc)], [None], [w.reshape(c, oc, 9)], [b], taps3, 1, 1, name='peaks.out_%s' % seq,
+                        out_nchw=g + 1)
+        P.head_channels = [c for _, _, c in heads]
+    finally:
+        _CACHE = None
+    P.cache = cache
+    return P
+
+
+def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3, dense_heads=None):
     kind, depth = parse_backbone(backbone)
     if H % 32 or W % 32:
         raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
@@ -364,6 +429,8 @@ def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3):
 
     # ---- heads (models/nets/header.py:13-46): the d6 convs of all G branches fused into one 256->G*256 conv
     heads = head_table(head_variant, num_classes)
+    if dense_heads is not None:
+        heads = heads[:int(dense_heads)]
     G = len(heads)
     h1 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h1')
     h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2')
@@ -630,6 +697,8 @@ class RealizedPlan(object):
             return any(s.tid == tid for s in op['inp']) or any(r is not None and r.tid == tid for r in op['res'])
         if op['op'] in ('maxpool', 'headout'):
             return op['inp'].tid == tid
+        if op['op'] == 'patch_mask':
+            return op['t'].tid == tid
         if op['op'] == 'softmax':
             return op['z_in'].tid == tid or any(u.tid == tid for u in op['us'])
         return False
@@ -770,6 +839,24 @@ class RealizedPlan(object):
         _lib.check(self.lib.rtm3d_op_maxpool(self.ctx, self.tids[op['inp'].tid], op['inp'].coff, self.tids[op['out'].tid],
                                              op['out'].coff, op['inp'].C, op['k'], op['stride'], op['pad']), 'op_maxpool ' + op['name'])
 
+    def _op_patch_mask(self, op):
+        if getattr(self, 'yx_blob', None) is None:
+            self.yx_blob = self._blob(np.full((self.plan.B, 2), -1, np.int32))
+        Hm, Wm = self.plan.map_hw
+        _lib.check(self.lib.rtm3d_op_patch_mask(self.ctx, self.tids[op['t'].tid], self.yx_blob, Hm, Wm, op['origin']), 'op_patch_mask')
+
+    def tensor_info(self, s):
+        """(device address of padded element [0][0][0][0], B, H, W, C, border) of the tensor a Slice lives in."""
+        base = ctypes.c_void_p()
+        v = [ctypes.c_int() for _ in range(5)]
+        _lib.check(self.lib.rtm3d_tensor_info(self.ctx, self.tids[s.tid], ctypes.byref(base), *[ctypes.byref(x) for x in v]), 'tensor_info')
+        return (base.value,) + tuple(x.value for x in v)
+
+    def blob_address(self, bid):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _lib.check(self.lib.rtm3d_blob_address(self.ctx, bid, ctypes.byref(p), ctypes.byref(n)), 'blob_address')
+        return p.value
+
     def _op_softmax(self, op):
         us = (ctypes.c_int * len(op['us']))(*[self.tids[u.tid] for u in op['us']])
         _lib.check(self.lib.rtm3d_op_softmax_fuse(self.ctx, self.tids[op['z_in'].tid], self.tids[op['z_out'].tid], len(op['us']), us),
@@ -836,6 +923,10 @@ class RealizedPlan(object):
         return out
 
     def close(self):
+        peak = getattr(self, 'peak', None)
+        if peak is not None:
+            peak.close()
+            self.peak = None
         if self.ctx:
             self.lib.rtm3d_ctx_destroy(self.ctx)
             self.ctx = None

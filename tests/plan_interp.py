@@ -10,12 +10,17 @@ import numpy as np
 import torch
 
 
-def run_plan(plan, x_nchw, half=False):
+def run_plan(plan, x_nchw, half=False, prefill=None, yx=None):
+    """prefill: {tensor id: (B, H, W, C) array} written into the interior of plan tensors before the first op (patch plans);
+    yx: (B, 2) peak (y, x) per slot for `patch_mask` ops, -1 = empty slot."""
     B = plan.B
     rnd = (lambda t: t.half().float()) if half else (lambda t: t)
     bufs = []
     for t in plan.tensors:
         bufs.append(torch.zeros(B, t['H'] + 2 * t['pad'], t['W'] + 2 * t['pad'], t['C']))
+    for tid, arr in (prefill or {}).items():
+        t = plan.tensors[tid]
+        bufs[tid][:, t['pad']:t['pad'] + t['H'], t['pad']:t['pad'] + t['W']] = rnd(torch.as_tensor(arr, dtype=torch.float32))
     outs = [None] * 4
 
     def view(s, extra=0):
@@ -68,6 +73,18 @@ def run_plan(plan, x_nchw, half=False):
             win = ibuf[:, Pi - p: Pi - p + (Ho - 1) * s + k, Pi - p: Pi - p + (Wo - 1) * s + k, i.coff:i.coff + i.C]
             y = torch.nn.functional.max_pool2d(win.permute(0, 3, 1, 2), k, s)
             obuf[:, Po:Po + Ho, Po:Po + Wo, o.coff:o.coff + o.C] = y.permute(0, 2, 3, 1)
+        elif op['op'] == 'patch_mask':
+            buf, Pp, S, _ = view(op['t'])
+            Hm, Wm = plan.map_hw
+            for s_ in range(B):
+                py, px = int(yx[s_][0]), int(yx[s_][1])
+                if py < 0:
+                    continue
+                for i in range(S):
+                    for j in range(S):
+                        y, x = py + i - op['origin'], px + j - op['origin']
+                        if not (0 <= y < Hm and 0 <= x < Wm):
+                            buf[s_, i, j] = 0
         elif op['op'] == 'softmax':
             zi, zo = op['z_in'], op['z_out']
             zb, Pz, H, W = view(zi)

@@ -633,6 +633,52 @@ def test_nonfinite_logits_through_decode2d_decode3d_pack(dev):
     assert (r[bad, 31] == 1).all() and (r[good_kept, 31] == 2).all() and (rec[0, n:] == 0).all()
 
 
+@pytest.mark.parametrize('bb,B,H,W,hb', [('RESNET-18', 3, 128, 256, -3.0), ('DLA-34', 2, 128, 256, -3.0), ('DLA-34', 1, 64, 128, 1.5),
+                                        ('DLA-34', 8, 384, 1280, -5.0)])
+def test_sparse_heads_equal_dense_heads_at_the_peaks(dev, bb, B, H, W, hb):
+    """Peaks-only regression heads (detect3d(sparse_heads=True), csrc/sparse_heads.hip) against the dense path of the same
+    model on the same images: the heat-map branch is the same kernels on the same operands, so detections (count, class,
+    score, cell) are IDENTICAL; the regression logits at the peaks come from the patch plan (other tile shapes, same fp16
+    operands, fp32 accumulation in another order), so sub-pixel key points / vertices agree to fp16 round-off of two
+    256-channel layers: bar 0.05 px (the dense path itself is within 0.038 px of the fp32 reference), kept 3D boxes follow.
+    Border and corner peaks are forced by the heat bias of the third case (top-k saturates: 100 peaks on a 16 x 32 map)."""
+    from rtm3d_amd.model_utils import decode3d_slots
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=hb)
+    m = make_model(bb, sd)
+    x = weights.synth_images(B, H, W, seed=91).to(dev)
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
+    det_d, box_d, lg_d = m.detect3d(x, K)
+    det_s, box_s, lg_s = m.detect3d(x, K, sparse_heads=True)
+    torch.cuda.synchronize()
+    assert len(lg_s) == 1 and torch.equal(lg_s[0], lg_d[0])                     # the heat map: bit-identical
+    n = det_d.n.cpu().numpy()
+    assert np.array_equal(det_s.n.cpu().numpy(), n) and n.sum() >= 3 * B
+    tk = det_d.topk
+    worst_v, worst_m, on_border = 0.0, 0.0, 0
+    for b in range(B):
+        sl = slice(b * tk, b * tk + int(n[b]))
+        assert torch.equal(det_s.cls[sl], det_d.cls[sl]) and torch.equal(det_s.score[sl], det_d.score[sl])
+        md, ms = det_d.mproj[sl].cpu().numpy(), det_s.mproj[sl].cpu().numpy()
+        assert np.array_equal(np.floor(md / 4), np.floor(ms / 4))               # same cell
+        cell = np.floor(md / 4)
+        on_border += int(((cell[:, 0] == 0) | (cell[:, 1] == 0) | (cell[:, 0] == W // 4 - 1) | (cell[:, 1] == H // 4 - 1)).sum())
+        worst_m = max(worst_m, float(np.abs(md - ms).max()))
+        worst_v = max(worst_v, float(np.abs(det_d.verts[sl].cpu().numpy() - det_s.verts[sl].cpu().numpy()).max()))
+        bd, bs = det_d.bbox[sl].cpu().numpy(), det_s.bbox[sl].cpu().numpy()
+        assert np.abs(bd - bs).max() <= 0.05
+    record_measurement('sparse_heads_vs_dense', '%s_%dx%dx%d' % (bb, B, H, W), {'vert_linf_px': worst_v, 'mproj_linf_px': worst_m,
+                                                                                'detections': int(n.sum()), 'border_peaks': on_border})
+    assert worst_v <= 0.05 and worst_m <= 0.02, (worst_v, worst_m)
+    if hb > 0:
+        assert on_border >= 10                                                   # the masks and the zero fill were exercised
+    # 3D decode on both: same keep decisions wherever the objective is not within 2 % of the acceptance threshold
+    fd, fs = box_d.fun.cpu().numpy(), box_s.fun.cpu().numpy()
+    for b in range(B):
+        sl = slice(b * tk, b * tk + int(n[b]))
+        clear = np.abs(fd[sl] - 0.1) > 0.002
+        assert np.array_equal((fd[sl] < 0.1)[clear], (fs[sl] < 0.1)[clear])
+
+
 def test_pipeline_rejects_wrong_batch(dev):
     """a shard larger than the preallocated slots would be an out-of-bounds device write, a smaller one
     would leave stale detections in the unused rows - both must raise before anything is launched."""

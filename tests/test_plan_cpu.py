@@ -124,3 +124,48 @@ def test_halo_kernel_selection():
         assert all(op['name'].startswith('backbone.level3.') and (op['Hm'], op['Wm']) == (48, 160) for op in c128)
     P = plan_mod.build_plan(sd, 'DLA-34', 32, 128, 256)         # 16 x 32 level3 map: 8 x 32 tiles fit, but only 64 of them
     assert not any(plan_mod.conv128_eligible(op, 32) for op in P.ops if op['op'] == 'conv')
+
+
+def gather_patches_reference(z, peaks):
+    """z: (B, C, H, W) fp32 fused map; peaks: [(b, y, x)] -> (n, 15, 15, C) patches in the layout of csrc/sparse_heads.hip: patch
+    pixel (5a + i, 5b + j) = z(y + i - 2 + 6(a - 1), x + j - 2 + 6(b - 1)), zero outside the map."""
+    B, C, H, W = z.shape
+    out = np.zeros((len(peaks), 15, 15, C), np.float32)
+    for s, (b, y, x) in enumerate(peaks):
+        for r in range(15):
+            for c in range(15):
+                zy, zx = y + r % 5 - 2 + 6 * (r // 5 - 1), x + c % 5 - 2 + 6 * (c // 5 - 1)
+                if 0 <= zy < H and 0 <= zx < W:
+                    out[s, r, c] = z[b, :, zy, zx]
+    return out
+
+
+def test_peak_plan_equals_dense_heads_at_the_peaks():
+    """Peaks-only regression heads (plan.build_peak_plan, csrc/sparse_heads.hip): the patch plan evaluated on the gathered
+    samples of the fused map z gives, for every peak - interior, on every border, in every corner - the value the DENSE
+    offset_fr_main / main_offset maps have at that peak (fp32, CPU plan interpreter: the algebra of the patch layout, the
+    {0, 5, 10} taps and the zero-padding masks), and the heat-map-only dense plan gives the dense plan's heat map."""
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 5, 'trained')
+    B, H, W = 2, 64, 128
+    x = weights.synth_images(B, H, W, seed=3)
+    dense = plan_mod.build_plan(sd, bb, B, H, W)
+    outs, fetch = run_plan(dense, x)
+    z = fetch(dense.named['z']).numpy()
+    Hm, Wm = H // 4, W // 4
+    hm_only = plan_mod.build_plan(sd, bb, B, H, W, dense_heads=1)
+    outs1, _ = run_plan(hm_only, x)
+    assert outs1[1] is None and torch.equal(outs1[0], outs[0])
+    peaks = [(0, 0, 0), (0, 0, Wm - 1), (1, Hm - 1, 0), (1, Hm - 1, Wm - 1), (0, 1, 1), (1, 0, 7), (0, 9, 0), (1, 8, Wm - 2),
+             (0, Hm - 2, 13), (1, 7, 15), (0, 5, 6), (1, 2, 2)]
+    slots = len(peaks) + 2                                  # two empty slots at the end
+    pp = plan_mod.build_peak_plan(sd, slots, (Hm, Wm))
+    patches = np.zeros((slots, 15, 15, 256), np.float32)
+    patches[:len(peaks)] = gather_patches_reference(z, peaks)
+    patches[len(peaks):] = 7.0                              # stale content of empty slots must not matter to anyone else
+    yx = np.array([[y, xx] for _, y, xx in peaks] + [[-1, -1]] * 2)
+    pouts, _ = run_plan(pp, None, prefill={pp.named['zp'].tid: patches}, yx=yx)
+    assert pouts[0].shape == (slots, 16, 1, 1) and pouts[1].shape == (slots, 2, 1, 1)
+    for s, (b, y, xx) in enumerate(peaks):
+        np.testing.assert_allclose(pouts[0][s, :, 0, 0].numpy(), outs[1][b, :, y, xx].numpy(), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(pouts[1][s, :, 0, 0].numpy(), outs[2][b, :, y, xx].numpy(), rtol=2e-4, atol=2e-4)
