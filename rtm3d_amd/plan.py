@@ -432,15 +432,17 @@ def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3, dens
     if dense_heads is not None:
         heads = heads[:int(dense_heads)]
     G = len(heads)
+    # (op names key the packed-weight cache: a plan with fewer dense branches packs other arrays under other names)
+    hn = 'heads' if dense_heads is None else 'heads[:%d]' % G
     h1 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h1')
     h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2')
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in heads])
-    P.conv(z, h1, np.concatenate(ws, 0), np.concatenate(bs, 0), dil=6, relu=True, name='heads.conv_d6')
+    P.conv(z, h1, np.concatenate(ws, 0), np.concatenate(bs, 0), dil=6, relu=True, name=hn + '.conv_d6')
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in heads])
     P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(G)], [P.sub(h2, g * oc, oc) for g in range(G)], ws, bs,
-                   relu=True, name='heads.conv_d1')
+                   relu=True, name=hn + '.conv_d1')
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%s' % (seq, last)) for seq, last, _ in heads])
-    P.headout(h2, ws, bs, name='heads.out_convs')
+    P.headout(h2, ws, bs, name=hn + '.out_convs')
     P.head_channels = [c for _, _, c in heads]
     return P
 

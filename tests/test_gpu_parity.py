@@ -647,10 +647,32 @@ def test_sparse_heads_equal_dense_heads_at_the_peaks(dev, bb, B, H, W, hb):
     m = make_model(bb, sd)
     x = weights.synth_images(B, H, W, seed=91).to(dev)
     K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
-    det_d, box_d, lg_d = m.detect3d(x, K)
+    _, _, lg_d = m.detect3d(x, K)
     det_s, box_s, lg_s = m.detect3d(x, K, sparse_heads=True)
     torch.cuda.synchronize()
-    assert len(lg_s) == 1 and torch.equal(lg_s[0], lg_d[0])                     # the heat map: bit-identical
+    if hb > 0:
+        # peaks planted on every border and in every corner of the map (on top of the network's own): the gather's zero fill
+        # beyond the padded tensor and both zero-padding masks decide these
+        hm = lg_s[0].clone()
+        Hm, Wm = H // 4, W // 4
+        cells = [(0, 0), (0, Wm - 1), (Hm - 1, 0), (Hm - 1, Wm - 1)] + [(0, c) for c in range(3, Wm - 2, 4)] + \
+                [(Hm - 1, c) for c in range(2, Wm - 2, 4)] + [(r, 0) for r in range(2, Hm - 2, 3)] + [(r, Wm - 1) for r in range(3, Hm - 2, 3)] + \
+                [(1, 1), (1, Wm - 2), (Hm - 2, 1), (Hm - 2, Wm - 2)]
+        for k_, (r, c) in enumerate(cells):
+            hm[0, k_ % 3, max(r - 1, 0):r + 2, max(c - 1, 0):c + 2] = -9.0
+            hm[0, k_ % 3, r, c] = 6.0 + 0.01 * k_
+        lg_s = (hm,)
+        det_s = m.decode2d_sparse(lg_s)             # the plan still holds z of the forward above
+        box_s = decode3d_slots(det_s, K, m.config.DETECTOR.dim_ref, [0, -0.5, 20])
+        torch.cuda.synchronize()
+        lg_d = (hm,) + tuple(lg_d[1:])
+    # the heat map: the same layers on the same operands; a plan with one dense branch may pick another tile shape / split-K
+    # for a small launch, so equal to fp32 summation order (and fp16 re-rounding of the two hidden maps), not bit for bit
+    assert len(lg_s) == 1 and float((lg_s[0] - lg_d[0]).abs().max()) <= 2e-2 * max(1.0, float(lg_d[0].abs().max()))
+    # reference for the regression part: the dense decode fed THIS heat map and the dense regression maps
+    det_d = m.decode2d((lg_s[0], lg_d[1], lg_d[2]))
+    box_d = decode3d_slots(det_d, K, m.config.DETECTOR.dim_ref, [0, -0.5, 20])
+    torch.cuda.synchronize()
     n = det_d.n.cpu().numpy()
     assert np.array_equal(det_s.n.cpu().numpy(), n) and n.sum() >= 3 * B
     tk = det_d.topk
@@ -670,7 +692,7 @@ def test_sparse_heads_equal_dense_heads_at_the_peaks(dev, bb, B, H, W, hb):
                                                                                 'detections': int(n.sum()), 'border_peaks': on_border})
     assert worst_v <= 0.05 and worst_m <= 0.02, (worst_v, worst_m)
     if hb > 0:
-        assert on_border >= 10                                                   # the masks and the zero fill were exercised
+        assert on_border >= 20                                                   # the masks and the zero fill were exercised
     # 3D decode on both: same keep decisions wherever the objective is not within 2 % of the acceptance threshold
     fd, fs = box_d.fun.cpu().numpy(), box_s.fun.cpu().numpy()
     for b in range(B):
