@@ -551,6 +551,36 @@ def test_two_stream_pipeline_with_saturated_topk(dev):
         assert torch.equal(g_, ref)
 
 
+def test_two_stream_pipeline_with_sparse_heads_equals_serial_sparse_path(dev):
+    """Detect3DPipeline(sparse_heads=True): forward (heat map only) -> peaks -> patch plan -> finish on the main stream, 3D decode
+    and packing on the side stream, over several pipelined steps with different inputs: records equal to the serial
+    detect3d(sparse_heads=True) + pack of the same batch, bit for bit (the patch plan's buffers are per plan, the slots per
+    pipeline: nothing of step i may leak into step i + 1)."""
+    from rtm3d_amd import distributed as rdist
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    bb = 'RESNET-18'
+    m = make_model(bb, weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5))
+    B = 3
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), device=dev)
+    xs = [weights.synth_images(B, 64, 128, seed=500 + 11 * i).to(dev) for i in range(4)]
+    pipe = Detect3DPipeline(m, B, dev, gather=False, sparse_heads=True)
+    got = {}
+    for i, x in enumerate(xs):
+        k = pipe.submit(x, K)
+        if k >= 1:
+            got[k - 1] = pipe.results(k - 1).clone()
+    got[len(xs) - 1] = pipe.results(len(xs) - 1).clone()
+    pipe.drain()
+    total = 0
+    for i, x in enumerate(xs):
+        det, boxes, _ = m.detect3d(x, K, sparse_heads=True)
+        ref = pack_records_reference(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, 100, boxes)
+        torch.cuda.synchronize()
+        assert torch.equal(got[i], ref), i
+        total += int(det.n.sum())
+    assert total >= 10
+
+
 def test_pack_records_hip_equals_reference(dev):
     """rtm3d_pack_records (one HIP launch) against the plain-torch definition of the record: every field incl. the fp64
     atan2, the kept flag at the fun < 0.1 edge and the zeroing of empty slots."""
