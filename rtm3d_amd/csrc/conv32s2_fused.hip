@@ -22,7 +22,7 @@
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
 #define S2_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
-__global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args a, unsigned int* ticket_ctr) {
+__global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args a, unsigned int* ticket_ctr, const int single) {
     __shared__ __attribute__((aligned(128))) f16 lds[2 * S2_BUF_PIECES * 8];
     __shared__ int tk[3];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,10 +59,17 @@ __global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args 
 
     // (ONE draw of three: three separate returning atomics per workgroup - 768 on one word, three round trips in a row
     // before the first MFMA - cost 8-10 us per launch; the word serves ~88 draws per microsecond)
-    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
-    __syncthreads();
-    const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
-    int cur = tk0, nxt = tk0 + 1, nn = tk0 + 2;
+    // `single` (no more work items than CUs: small batches): workgroup b takes item b and nothing else - with three tickets per
+    // draw only a third of the workgroups would work, three items each in a row (bs=1 at 384 x 1280: 40 of 120)
+    int cur, nxt, nn;
+    if (single) {
+        cur = blockIdx.x; nxt = nn = total;
+    } else {
+        if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
+        __syncthreads();
+        const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
+        cur = tk0; nxt = tk0 + 1; nn = tk0 + 2;
+    }
     if (cur >= total) return;
     __syncthreads();
 
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args 
 #pragma unroll
             for (int c = 0; c < 2; ++c) accp[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wproj[c], pool, accp[c][p], 0, 0, 0);
         }
-        if (tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
+        if (!single && tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
 
         // ---- epilogue of `cur`: mid = ReLU(conv + bias) and residual = project + bias, 16-byte swapped stores
         {
@@ -156,6 +163,6 @@ __global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args 
 hipError_t launch_conv32s2_fused(const Conv32S2Args& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s) {
     const int total = a.B * (a.Wo >> 5) * (a.Ho >> 3);
     const int grid = cu_count < total ? cu_count : total;
-    hipLaunchKernelGGL(conv32s2_fused_kernel, dim3(grid), dim3(512), 0, s, a, ticket_ctr);
+    hipLaunchKernelGGL(conv32s2_fused_kernel, dim3(grid), dim3(512), 0, s, a, ticket_ctr, total <= cu_count ? 1 : 0);
     return hipGetLastError();
 }

@@ -27,7 +27,7 @@
 #define C64_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 template <int RES>
-__global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, unsigned int* ticket_ctr) {
+__global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, unsigned int* ticket_ctr, const int single) {
     __shared__ __attribute__((aligned(128))) f16 lds[2 * C64_BUF_PIECES * 8];
     __shared__ int tk[3];
     const int tid = threadIdx.x;
@@ -74,10 +74,17 @@ __global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, uns
     // every forward.
     // (ONE draw of three: three separate returning atomics per workgroup - 768 on one word, three round trips in a row
     // before the first MFMA - cost 8-10 us per launch; the word serves ~88 draws per microsecond)
-    if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
-    __syncthreads();
-    const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
-    int cur = tk0, nxt = tk0 + 1, nn = tk0 + 2;
+    // `single` (no more work items than CUs: small batches): workgroup b takes item b and nothing else - with three tickets per
+    // draw only a third of the workgroups would work, three items each in a row (bs=1 at 384 x 1280: 40 of 120)
+    int cur, nxt, nn;
+    if (single) {
+        cur = blockIdx.x; nxt = nn = total;
+    } else {
+        if (tid == 0) tk[0] = (int)atomicAdd(ticket_ctr, 3u);
+        __syncthreads();
+        const int tk0 = __builtin_amdgcn_readfirstlane(tk[0]);
+        cur = tk0; nxt = tk0 + 1; nn = tk0 + 2;
+    }
     if (cur >= total) return;
     __syncthreads();                                // tk[0..1] are reused as the per-tile slots below
 
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, uns
         }
         // one more ticket (for the tile after `nn`): drawn here, where this wave's DMA has long landed (the compiler
         // waits for the returning atomic with vmcnt(0)); slot it & 1 was read by everyone two barriers ago
-        if (tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
+        if (!single && tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
 
         // ---- epilogue of `cur`
         {
@@ -204,7 +211,7 @@ bool conv64_halo_supported(const ConvKArgs& a, int groups) {
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s) {
     const int total = (a.M / a.HmWm) * (a.Wm >> 5) * ((a.HmWm / a.Wm) >> 3);
     int grid = cu_count < total ? cu_count : total;
-    if (a.res) hipLaunchKernelGGL(conv64_halo_kernel<1>, dim3(grid), dim3(512), 0, s, a, ticket_ctr);
-    else hipLaunchKernelGGL(conv64_halo_kernel<0>, dim3(grid), dim3(512), 0, s, a, ticket_ctr);
+    if (a.res) hipLaunchKernelGGL(conv64_halo_kernel<1>, dim3(grid), dim3(512), 0, s, a, ticket_ctr, total <= cu_count ? 1 : 0);
+    else hipLaunchKernelGGL(conv64_halo_kernel<0>, dim3(grid), dim3(512), 0, s, a, ticket_ctr, total <= cu_count ? 1 : 0);
     return hipGetLastError();
 }
