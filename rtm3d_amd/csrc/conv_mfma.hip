@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         }
     }
     const f16* wbase = a.wgt + g.w_off + (size_t)ntile * a.ksteps * (BN * 64);
+    // a 1x1 conv with ONE channel tile reads every input byte once: non-temporal DMA (aux = 2) for the pixel operand, so the
+    // stream does not push the weights and the neighbours' lines out of L2 / the Infinity Cache (same-box A/B, profiles/r03_ab_nt.txt:
+    // level3 roots 0.044 -> 0.041 ms, the neck's 320 -> 256 1x1 0.249 -> 0.226; with several channel tiles or taps the operand is
+    // re-read through L2 and nt costs: the logit convs' halo staging 0.512 -> 0.553 ms)
+    const bool x_once = a.ntaps == 1 && a.NT == 1 && a.in_stride == 1;
 
     auto stage = [&](int buf, int ks) {
         const int tap = ks / a.cpt, q = ks - tap * a.cpt;
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const f16* src = a.in + (size_t)xoff[i] + (ptrdiff_t)koff;
-            __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)(xl + (i * 256 + wave * 64) * 8), 16, 0, 0);
+            if (x_once) __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)(xl + (i * 256 + wave * 64) * 8), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)(xl + (i * 256 + wave * 64) * 8), 16, 0, 0);
         }
         const f16* ws = wbase + (size_t)ks * (BN * 64);
         f16* wl = xl + BM * 64;

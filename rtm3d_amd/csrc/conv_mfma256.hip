@@ -242,6 +242,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // handed to a ds_read whose data lands before a queued MFMA has read them as SrcC: conv_mfma256_halo.hip).
 #define DMA16(gptr, lds_byte_addr) \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define DMA16_NT(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LOAD_X_N(SLOT)                                                                      \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
     };
     bool live_n;
+    const bool x_once = a.ntaps == 1 && a.NT == 1 && a.in_stride == 1;      // single-read pixel operand: nt DMA (see conv_mfma.hip)
     locate(v, xo_c, wb_c, gi_c, mt_c, nt_c);
     // until the real successor is located (after the first K-tile) "n" aliases "c"
     xo_n[0][0] = xo_c[0][0]; xo_n[0][1] = xo_c[0][1]; xo_n[1][0] = xo_c[1][0]; xo_n[1][1] = xo_c[1][1];
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             for (int i = 0; i < 2; ++i) {
                 const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
                 const f16* src = a.in + (size_t)xo + (ptrdiff_t)koff;
-                DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                if (x_once) DMA16_NT(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                else DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
             }
         } else {
             const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;

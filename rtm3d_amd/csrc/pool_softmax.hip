@@ -141,9 +141,10 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int xx = x + 8 * k < x1 ? x + 8 * k : x;
-                zi[k] = *(const f16x8*)(a.z_in + zirow + (size_t)xx * a.zi_C);
+                // non-temporal: the 2 GB of z_in and u are read exactly once (same-box A/B, profiles/r03_ab_nt.txt: 0.550 -> 0.509 ms)
+                zi[k] = __builtin_nontemporal_load((const f16x8*)(a.z_in + zirow + (size_t)xx * a.zi_C));
 #pragma unroll
-                for (int ui = 0; ui < NU; ++ui) v[k][ui] = *(const f16x8*)(a.u[ui] + urow[ui] + (size_t)xx * a.u_C[ui]);
+                for (int ui = 0; ui < NU; ++ui) v[k][ui] = __builtin_nontemporal_load((const f16x8*)(a.u[ui] + urow[ui] + (size_t)xx * a.u_C[ui]));
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void softmax_apply_kernel(const SoftmaxKArgs a
                     }
                     o[e] = (f16)acc;
                 }
+                // (a non-temporal STORE here was measured too: the head conv that reads z next went 3.72 -> 4.06 ms)
                 *(f16x8*)(a.z_out + zrow + (size_t)(x + 8 * k) * a.z_C) = o;
             }
         }
