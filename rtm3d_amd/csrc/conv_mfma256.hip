@@ -294,7 +294,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         sp ^= 1;                                                                            \
     }
 
-template <int RES>
+// XNT = 1: a 1x1 conv with one channel tile reads every input byte once - its pixel operand goes through a non-temporal DMA
+// (see conv_mfma.hip).  A template parameter, not a run-time flag: as a flag it cost the head convs 12 SGPRs and 20 B of scratch.
+template <int RES, int XNT>
 __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS + 4];   // + two ticket words
@@ -363,7 +365,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
     };
     bool live_n;
-    const bool x_once = a.ntaps == 1 && a.NT == 1 && a.in_stride == 1;      // single-read pixel operand: nt DMA (see conv_mfma.hip)
     locate(v, xo_c, wb_c, gi_c, mt_c, nt_c);
     // until the real successor is located (after the first K-tile) "n" aliases "c"
     xo_n[0][0] = xo_c[0][0]; xo_n[0][1] = xo_c[0][1]; xo_n[1][0] = xo_c[1][0]; xo_n[1][1] = xo_c[1][1];
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             for (int i = 0; i < 2; ++i) {
                 const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
                 const f16* src = a.in + (size_t)xo + (ptrdiff_t)koff;
-                if (x_once) DMA16_NT(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                if (XNT) DMA16_NT(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
                 else DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
             }
         } else {
@@ -562,8 +563,10 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
         dim3 grid(per_xcd * 8, 1, 1);
-        if (a.res) hipLaunchKernelGGL(conv_mfma256_persistent_kernel<1>, grid, block, 0, s, a, groups, nbias, tile_ctr);
-        else hipLaunchKernelGGL(conv_mfma256_persistent_kernel<0>, grid, block, 0, s, a, groups, nbias, tile_ctr);
+        const bool x_once = !a.res && a.ntaps == 1 && a.NT == 1 && a.in_stride == 1;
+        if (a.res) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<1, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr);
+        else if (x_once) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 1>), grid, block, 0, s, a, groups, nbias, tile_ctr);
+        else hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr);
         return hipGetLastError();
     }
     if (stat_out) return hipErrorInvalidValue;       // only the halo kernel writes softmax partials
