@@ -29,6 +29,9 @@
 //     instead makes the allocator split the file 128/128 and spill.  A static first item per workgroup: same speed alone,
 //     slower with the 3D decode beside it.);
 //     consecutive items are the channel tiles of one pixel tile (shared halo in L2);
+//   * (round 3, measured and not kept: the wave's bias values loaded once before the item loop instead of in every epilogue, so
+//     that no compiler-visible vector-memory load - and no s_waitcnt vmcnt(0) in front of the epilogue arithmetic - is left
+//     there: 0.074 / 0.087 ms with and without, same box; the drain is not what an item waits for);
 //   * epilogue: bias (+ residual) + ReLU, v_permlane16_swap pairs two 16-channel MFMA tiles -> 16-byte stores.  (Keeping the
 //     previous tile's stores and this tile's residual loads in flight across the first K-steps, with the wait counts
 //     raised accordingly, was measured: no change - the residual layers are 12 us slower because they move 63 MB more.)
