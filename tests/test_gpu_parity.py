@@ -551,6 +551,27 @@ def test_two_stream_pipeline_with_saturated_topk(dev):
         assert torch.equal(g_, ref)
 
 
+def test_model_detect_gives_the_lists_of_forward(dev):
+    """Model.detect(x) = what detect.py:56 takes (`model(imgs)[0]`), through the peaks-only regression heads: same per-image
+    lists (None for an empty image), classes / scores identical, key points / vertices / boxes to fp16 round-off."""
+    bb = 'RESNET-18'
+    m = make_model(bb, weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.5))
+    x = weights.synth_images(3, 64, 128, seed=12).to(dev)
+    x[1] = 0                                        # an image without detections? (decided by the heat map; either way both agree)
+    ref = m(x)[0]
+    got = m.detect(x)
+    assert len(got) == 5
+    for b in range(3):
+        if ref[0][b] is None:
+            assert all(g[b] is None for g in got)
+            continue
+        # (the heat-map-only plan may pick other tile shapes for a small launch: scores to fp32 summation order, not bit for bit)
+        assert torch.equal(got[0][b], ref[0][b]) and float((got[1][b] - ref[1][b]).abs().max()) <= 2e-3
+        for k in (2, 3, 4):
+            assert float((got[k][b] - ref[k][b]).abs().max()) <= 0.05
+    assert any(r is not None for r in ref[0])
+
+
 def test_two_stream_pipeline_with_sparse_heads_equals_serial_sparse_path(dev):
     """Detect3DPipeline(sparse_heads=True): forward (heat map only) -> peaks -> patch plan -> finish on the main stream, 3D decode
     and packing on the side stream, over several pipelined steps with different inputs: records equal to the serial
