@@ -308,6 +308,20 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2):
             st_boxd.extend(list(dv))
             st['box_linf'] = max(st['box_linf'], float(dv.max()))
     st['boxes'] = _box_stats(st_boxd)
+    # the same stage inputs through the solver's PUBLISHED form (L-BFGS-B's subspace step, the form SciPy runs; kept as a
+    # cross-check kernel): tells an implementation difference of the product's direct two-loop form from an object on which any
+    # two correct implementations stop an iteration apart
+    from rtm3d_amd.model_utils import solve_boxes
+    pub_boxd, pub_nit = [], 0
+    for b in range(k):
+        if raws_p[b] is None:
+            continue
+        xp, fp_, nitp, _ = solve_boxes(dets_p[0][b].numpy(), dets_p[3][b].numpy(), K, dim_ref, [0, -0.5, 20], device=dev, reference_form=True)
+        both = raws_p[b]['kept'] & (fp_ < 0.1)
+        pub_nit += int((nitp != raws_p[b]['nit'])[both].sum())
+        if both.any():
+            pub_boxd.extend(list(angle_diff(box_params(xp[both]), box_params(raws_p[b]['x'][both]))))
+    st['published_form'] = {'boxes': _box_stats(pub_boxd), 'iteration_count_differs': pub_nit}
     out['stage'] = st
     # ---------------------------------------------------------------- end to end (fp16 network on the device)
     def match_e2e(det, boxes, dets_o, raws, only_cells=None):
