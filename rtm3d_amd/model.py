@@ -186,14 +186,15 @@ class Model(object):
             x = x.float()
         return x.contiguous()
 
-    def input_tensor(self, B, H, W, device=None):
+    def input_tensor(self, B, H, W, device=None, heads='dense'):
         """(device address, border) of the fp16 NHWC4 input tensor of the plan for (B, H, W): the target of
-        ``rtm3d_amd.preprocess.preprocess_batch(..., model=self)``."""
+        ``rtm3d_amd.preprocess.preprocess_batch(..., model=self)``.  heads: which plan ('dense' / 'peaks': they own separate
+        workspaces) the following ``forward_logits(None, preloaded=..., heads=...)`` will replay."""
         dev = torch.device(device) if device is not None else self._device
         if dev is None or dev.type != 'cuda':
             raise RuntimeError('rtm3d_amd.Model.input_tensor needs a CUDA (ROCm) device; call model.to("cuda") first')
         dev = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
-        return self._plan_for(B, H, W, dev).input_tensor()
+        return self._plan_for(B, H, W, dev, heads).input_tensor()
 
     def forward_logits(self, x, preloaded=None, out=None, heads='dense'):
         """backbone -> neck -> heads: the four fp32 NCHW logit maps (models/model.py:21-23).

@@ -104,7 +104,7 @@ class Detect3DPipeline(object):
         H, W = int(size[0]), int(size[1])
 
         def feed():
-            preprocess.preprocess_batch(images, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=resize_to, model=self.model)
+            preprocess.preprocess_batch(images, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=resize_to, model=self.model, heads=self.heads)
             return self.model.forward_logits(None, preloaded=(self.B, H, W), out='reuse', heads=self.heads)
         return self._submit(feed, K_per_image)
 

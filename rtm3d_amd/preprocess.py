@@ -102,11 +102,12 @@ def resize_K(K, hw, new_hw):
     return K
 
 
-def preprocess_batch(images, size, mean, std, resize_to=None, out=None, model=None):
+def preprocess_batch(images, size, mean, std, resize_to=None, out=None, model=None, heads='dense'):
     """images: list of uint8 CUDA tensors (h, w, 3), any sizes.  size = (H, W) network canvas.
     resize_to: None (images are already resized) or the reference's INPUT_SIZE (longest side after Resize).
     model given: write straight into that model's fp16 NHWC4 input tensor for batch (B, H, W) - call
-    ``model.forward_logits(None, preloaded=(B, H, W))`` next; otherwise returns the fp32 (B,3,H,W) batch.
+    ``model.forward_logits(None, preloaded=(B, H, W), heads=heads)`` next (heads: the plan that forward will replay);
+    otherwise returns the fp32 (B,3,H,W) batch.
     Returns (out or None, [(pad_w, pad_h)], [(h', w')])."""
     lib = _lib.load()
     H, W = int(size[0]), int(size[1])
@@ -131,7 +132,7 @@ def preprocess_batch(images, size, mean, std, resize_to=None, out=None, model=No
         sums = torch.zeros(B, 3, dtype=torch.int64, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if model is not None:
-            base, border = model.input_tensor(B, H, W, dev)
+            base, border = model.input_tensor(B, H, W, dev, heads)
             mode, dst, ret = 1, base, None
         else:
             if out is None:

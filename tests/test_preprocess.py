@@ -166,3 +166,14 @@ def test_pipeline_submit_uint8_equals_fp32_feed():
         assert torch.equal(ra, rb) and float(ra[:, :, 31].sum()) > 0
     with pytest.raises(ValueError):
         pipe_b.submit_uint8(imgs[:2], K, (H, W), resize_to=256)
+    # the same with the peaks-only regression heads: the uint8 feed must fill the input tensor of the plan that is replayed
+    # (the heat-map-only plan owns its own workspace)
+    pipe_c = Detect3DPipeline(m, B, dev, gather=False, sparse_heads=True)
+    pipe_d = Detect3DPipeline(m, B, dev, gather=False, sparse_heads=True)
+    for step in range(2):
+        imgs = [torch.from_numpy(rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)).to(dev) for hh, ww in ((180, 500), (100, 256), (120, 300))]
+        x32, _, _ = preprocess.preprocess_batch(imgs, (H, W), cfg.DATASET.MEAN, cfg.DATASET.STD, resize_to=256)
+        rc = pipe_c.results(pipe_c.submit(x32, K)).clone()
+        rd = pipe_d.results(pipe_d.submit_uint8(imgs, K, (H, W), resize_to=256)).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(rc, rd) and float(rc[:, :, 31].sum()) > 0
