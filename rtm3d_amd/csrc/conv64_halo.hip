@@ -14,6 +14,10 @@
 //   * tiles are handed out by one atomic ticket counter per op (zeroed at the head of every forward by the runtime), so a
 //     workgroup whose CU was still held by another stream's waves simply takes fewer tiles;
 //   * epilogue: bias (+ residual) + ReLU, v_permlane16_swap pairs the two 16-channel MFMA tiles -> 16-byte stores.
+// (Round 3, measured and removed: 8 x 16-pixel tiles on FOUR waves with two independent workgroups per CU, so that one multiplies
+// while the other runs its epilogue / waits for its halo - same per-wave arithmetic, 250 VGPRs, 2 x 23 KB of halo buffers: 0.106 ms
+// against 0.070 for the non-residual layers, 0.112 against 0.092 with a residual, same box.  Twice the items, half the row length
+// per DMA, 1.41x instead of 1.33x halo bytes: the per-item costs outweigh the overlap.)
 // K order: tap-major, 64 channels per tap as two 32-deep MFMAs (fp32 accumulate; the order of the sums differs from the
 // generic kernel's, results agree to fp32 round-off).
 #include "common.h"
