@@ -17,7 +17,11 @@
 // (Round 3, measured and removed: 8 x 16-pixel tiles on FOUR waves with two independent workgroups per CU, so that one multiplies
 // while the other runs its epilogue / waits for its halo - same per-wave arithmetic, 250 VGPRs, 2 x 23 KB of halo buffers: 0.106 ms
 // against 0.070 for the non-residual layers, 0.112 against 0.092 with a residual, same box.  Twice the items, half the row length
-// per DMA, 1.41x instead of 1.33x halo bytes: the per-item costs outweigh the overlap.)
+// per DMA, 1.41x instead of 1.33x halo bytes: the per-item costs outweigh the overlap.  The opposite, 16 x 32-pixel items (one (16+2) x
+// (32+2) halo = 1.195x, computed as two 8-row passes so that the registers stay as here; half the barriers, tickets and DMA bursts):
+// 0.076 against 0.070 without a residual, 0.089-0.094 against 0.090-0.095 with one.  Neither the item size nor the epilogue overlap is
+// what bounds these layers: a tile moves 75-107 KB through one CU's memory path in 4.7-6.1 us = 16-17.5 GB/s per CU, ~70 % of the
+// 23-25 GB/s a CU streams by LDS-DMA alone (MI355X_MICROARCH.md, ldsdma-fill).)
 // K order: tap-major, 64 channels per tap as two 32-deep MFMAs (fp32 accumulate; the order of the sums differs from the
 // generic kernel's, results agree to fp32 round-off).
 #include "common.h"
