@@ -915,8 +915,19 @@ def test_class_count_follows_dataset_objs(dev):
     with pytest.raises(IndexError):
         rtm3d_amd.model_utils.optim_decode_bbox3d(np.array([4]), np.zeros((1, 8, 2), np.float32), weights.synth_intrinsics(),
                                                   cfg.DETECTOR.dim_ref, [0, -0.5, 20])
-    det, boxes, _ = m.detect3d(x.to(dev), K, dim_ref=list(cfg.DETECTOR.dim_ref) + [[2.0, 1.9, 5.0], [3.2, 2.5, 9.0]])
+    dim5 = list(cfg.DETECTOR.dim_ref) + [[2.0, 1.9, 5.0], [3.2, 2.5, 9.0]]
+    det, boxes, _ = m.detect3d(x.to(dev), K, dim_ref=dim5)
     assert int(det.n.sum()) == int((boxes.status >= 0).sum())
+    # the peaks-only regression heads with five classes and another top-k (the patch plan has B * topk slots)
+    cfg.DETECTOR.TOPK_CANDIDATES = 37
+    det_d, _, _ = m.detect3d(x.to(dev), K, dim_ref=dim5)
+    det_s, box_s, lg = m.detect3d(x.to(dev), K, dim_ref=dim5, sparse_heads=True)
+    torch.cuda.synchronize()
+    assert lg[0].shape == (2, 5, 16, 32) and det_s.topk == 37 and torch.equal(det_s.n, det_d.n) and int(det_s.n.max()) <= 37
+    for b in range(2):
+        sl = slice(b * 37, b * 37 + int(det_d.n[b]))
+        assert torch.equal(det_s.cls[sl], det_d.cls[sl])
+        assert float((det_s.verts[sl] - det_d.verts[sl]).abs().max()) <= 0.05
 
 
 def test_project_boxes_device_vs_reference_vectors(dev):
