@@ -64,6 +64,7 @@ def parse_args():
                          'normalise on the device (two launches, straight into the fp16 input tensor) in front of the plan; once: the same images are '
                          'preprocessed once, outside the timed region, into the fp32 NCHW batch that is then fed like the BASELINE line (the A/B partner)')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
+    ap.add_argument('--bn-tile', action='append', default=[], metavar='OP=N', help='DIAGNOSTIC (A/B): output-channel tile (16/32/64/128) of the 128-pixel conv kernel for the op named OP (plan.BN_TILE_OVERRIDE)')
     ap.add_argument('--sparse-heads', action='store_true', help='DIAGNOSTIC (not the BASELINE line): the detect3d call surface with the regression head branches evaluated at the detected peaks only (Model.decode2d_sparse); Model.forward() and the headline keep all four dense maps')
     ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
@@ -574,6 +575,10 @@ def main():
     if args.no_conv128:
         from rtm3d_amd import plan as _plan
         _plan.USE_CONV128 = False
+    for spec in args.bn_tile:
+        from rtm3d_amd import plan as _plan
+        name, n = spec.rsplit('=', 1)
+        _plan.BN_TILE_OVERRIDE[name] = int(n)
     bb = args.backbone
     B, H, W = args.batch, args.height, args.width
     cfg = rtm3d_amd.kitti_config(bb)
@@ -733,6 +738,8 @@ def main():
             out['DIAGNOSTIC_v2_min_tiles'] = args.v2_min_tiles
         if args.no_conv128:
             out['DIAGNOSTIC_no_conv128'] = True
+        if args.bn_tile:
+            out['DIAGNOSTIC_bn_tile'] = args.bn_tile
         if args.from_uint8:
             out['config']['input'] = ('B uint8 360x1240x3 images in HBM -> Resize(1280, bilinear) + letterbox + normalise on the device (rtm3d_preprocess_batch, fp16 NHWC4 output) in every step'
                                       if args.from_uint8 == 'step' else 'the same uint8 images preprocessed ONCE outside the timed region into the fp32 NCHW batch fed in every step')

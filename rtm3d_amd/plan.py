@@ -545,6 +545,7 @@ def conv64_eligible(op):
             and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0)
 
 
+BN_TILE_OVERRIDE = {}     # DIAGNOSTIC (bench.py --bn-tile): op name -> output-channel tile of the 128-pixel kernel, for A/B runs
 USE_CONV128 = True
 C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small-launch kernels of conv_mfma.hip do better (ResNet-18 bs=8, 240 tiles: 3.87 ms per step on this kernel against 3.76)
 
@@ -814,7 +815,7 @@ class RealizedPlan(object):
             d.w_blob = self._blob(self._packed(op, 0, 'smallc%d' % rows, 0, lambda: pack_smallc_weights(op['w'][0], rows=rows)))
             d.bias_blob = self._blob(op['bias'][0])
         elif op['cin'] % 64 == 0:
-            bn = op.get('bn_tile') or choose_bn_tile(op['cout'], M)
+            bn = op.get('bn_tile') or BN_TILE_OVERRIDE.get(op['name']) or choose_bn_tile(op['cout'], M)
             packed, biases = [], []
             for g in range(G):
                 pw = self._packed(op, g, 'mfma', bn, lambda g=g: pack_mfma_weights(op['w'][g], bn)[0])
