@@ -226,6 +226,46 @@ def test_forward_logits_vs_reference_golden(dev, fname):
     assert checked >= 12 * B, checked       # the fixtures bite: ~20 detections per image with scores 0.4 .. 0.95
 
 
+@pytest.mark.parametrize('fname', E2E)
+def test_sparse_heads_detections_vs_reference_golden(dev, fname):
+    """Model.detect (peaks-only regression heads) against the REFERENCE's own detections of the reference-run e2e fixtures: as
+    for the dense path, every reference detection whose heat-map logit is further than the logit tolerance from the threshold is
+    found at the same (class, y, x) with its vertices within VERT_TOL_PX."""
+    g = load_golden(fname)
+    bb = str(g['backbone'])
+    B, H, W = [int(v) for v in g['shape']]
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
+    x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
+    m = make_model(bb, sd)
+    clses, scores, mprojs, verts, boxes = m.detect(x.to(dev))
+    tol = HM_RTOL * max(1.0, np.abs(g['logits_main_kf']).max())
+    thr_logit = float(np.log(0.4 / 0.6))
+    n = g['det_n']
+    checked, vmax = 0, 0.0
+    for b in range(B):
+        if n[b] == 0:
+            continue
+        rc, rs, rm, rv, _ = dets_from_golden(g, 'det_', b)
+        margin = np.abs(np.log(rs.astype(np.float64) / (1.0 - rs.astype(np.float64))) - thr_logit)
+        sure = margin > tol
+        if clses[b] is None:
+            assert not sure.any()
+            continue
+        got = {(int(c), int(mx // 4), int(my // 4)): v for c, (mx, my), v in
+               zip(clses[b].cpu().numpy(), mprojs[b].cpu().numpy(), verts[b].cpu().numpy())}
+        for c, s_, mp, v, ok in zip(rc, rs, rm, rv, sure):
+            if not ok:
+                continue
+            key = (int(c), int(mp[0] // 4), int(mp[1] // 4))
+            assert key in got, (key, s_)
+            vmax = max(vmax, float(np.abs(got[key] - v).max()))
+            checked += 1
+    record_measurement('sparse_heads_detections_vs_reference_golden', fname, {'matched': checked, 'reference_detections': int(n.sum()),
+                                                                              'vertex_linf_px': vmax})
+    assert vmax < VERT_TOL_PX, vmax
+    assert checked >= 12 * B, checked
+
+
 @pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
 def test_forward_stages_vs_oracle(dev, bb):
     """Fresh seed, batch 3, non-square small input: backbone features, fused map and logits."""
