@@ -9,3 +9,9 @@ run --batch 1 --steps 20000 --warmup 50
 run --backbone RESNET-18 --batch 8 --steps 5000 --warmup 20
 run --steps 500 --warmup 10 --heat-bias 2
 run --backbone RESNET-34 --batch 4 --steps 2000 --warmup 20
+# round 3: the same with the peaks-only regression heads (patch plan + gather + finish per step), and the uint8 feed
+run --steps 2000 --warmup 10 --sparse-heads
+run --batch 1 --steps 10000 --warmup 50 --sparse-heads
+run --backbone RESNET-18 --batch 8 --steps 3000 --warmup 20 --sparse-heads
+run --steps 500 --warmup 10 --heat-bias 2 --sparse-heads
+run --steps 500 --warmup 10 --from-uint8 step --sparse-heads
