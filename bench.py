@@ -65,6 +65,7 @@ def parse_args():
                          'preprocessed once, outside the timed region, into the fp32 NCHW batch that is then fed like the BASELINE line (the A/B partner)')
     ap.add_argument('--graph', action='store_true', help='DIAGNOSTIC (A/B): replay the plan as one hipGraph (the live roofline probe needs the eager replay, so launch_ms then comes from the per-op pass)')
     ap.add_argument('--bn-tile', action='append', default=[], metavar='OP=N', help='DIAGNOSTIC (A/B): output-channel tile (16/32/64/128) of the 128-pixel conv kernel for the op named OP (plan.BN_TILE_OVERRIDE)')
+    ap.add_argument('--no-sparse-probe', action='store_true', help='skip the informational detect_surface_sparse_heads block (a few pipelined steps of the peaks-only mode after the timed region)')
     ap.add_argument('--sparse-heads', action='store_true', help='DIAGNOSTIC (not the BASELINE line): the detect3d call surface with the regression head branches evaluated at the detected peaks only (Model.decode2d_sparse); Model.forward() and the headline keep all four dense maps')
     ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
@@ -772,6 +773,25 @@ def main():
             out['parity'] = parity_check(model, cfg, sd, bb, x, args.parity_images, dev)
         else:
             out['parity'] = None
+        if (not args.no_sparse_probe and world == 1 and pipe is not None and not args.sparse_heads and not args.from_uint8
+                and not args.diag_no_decode3d and model._head_variant in (None, 'rtm3d')):
+            # informational, outside the timed region and never `value`: the same batch through the detect3d call surface with the
+            # regression heads evaluated at the detected peaks only (what `bench.py --sparse-heads` times as a DIAGNOSTIC line)
+            try:
+                sp = Detect3DPipeline(model, B, dev, gather=False, sparse_heads=True)
+                for _ in range(3):
+                    sp.submit(x, K)
+                sp.drain(); torch.cuda.synchronize(dev)
+                ns = max(5, min(args.steps, 20))
+                t1 = time.perf_counter()
+                for _ in range(ns):
+                    sp.submit(x, K)
+                sp.drain(); torch.cuda.synchronize(dev)
+                dts = time.perf_counter() - t1
+                out['detect_surface_sparse_heads'] = {'DIAGNOSTIC': 'not the BASELINE metric: Model.forward() and `value` keep four dense logit maps',
+                                                      'images_per_s': B * ns / dts, 'ms_per_step': dts / ns * 1e3, 'steps': ns}
+            except Exception as e:                 # the probe must never cost the line
+                out['detect_surface_sparse_heads'] = {'error': repr(e)[:200]}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
