@@ -612,6 +612,22 @@ def test_model_detect_gives_the_lists_of_forward(dev):
     assert any(r is not None for r in ref[0])
 
 
+def test_sparse_heads_with_no_detections(dev):
+    """Empty images through the peaks-only path: no peak above the threshold anywhere -> every slot is empty, the patch plan runs
+    on whatever its buffers hold and nobody reads its results: counts 0, lists None, records all zero, no 3D solve."""
+    from rtm3d_amd import distributed as rdist
+    bb = 'RESNET-18'
+    m = make_model(bb, weights.synth_state_dict(bb, 1, 'trained', heat_bias=-30.0))
+    x = weights.synth_images(2, 64, 128, seed=3).to(dev)
+    K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (2, 1)), device=dev)
+    m.detect3d(weights.synth_images(2, 64, 128, seed=4).to(dev), K, sparse_heads=True)        # leave something in the patch buffers
+    det, boxes, _ = m.detect3d(x, K, sparse_heads=True)
+    rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, det.topk, boxes)
+    torch.cuda.synchronize()
+    assert det.n.cpu().tolist() == [0, 0] and (boxes.status.cpu().numpy() == -1).all() and float(rec.abs().sum()) == 0.0
+    assert all(v == [None, None] for v in m.detect(x))
+
+
 def test_two_stream_pipeline_with_sparse_heads_equals_serial_sparse_path(dev):
     """Detect3DPipeline(sparse_heads=True): forward (heat map only) -> peaks -> patch plan -> finish on the main stream, 3D decode
     and packing on the side stream, over several pipelined steps with different inputs: records equal to the serial
