@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
+    ap.add_argument('--rehearse-one-gpu', action='store_true', help='DIAGNOSTIC: the N ranks of --gpus N all run on GPU 0 and exchange their records over gloo through host memory (RCCL refuses duplicate devices): the whole N > 1 code path - shards, pipelined gather, ordering, diagnostics - on a one-GPU box; the line is marked INVALID')
     ap.add_argument('--dry-launch', action='store_true', help='launcher rehearsal over gloo on CPU tensors, no GPU and no hot path (line marked INVALID)')
     return ap.parse_args()
 
@@ -480,17 +481,21 @@ def multi_diagnostics(world, B, steps, dt, rec, local, dev, gather_us):
     """Diagnostics of an N-rank run, outside the timed region: max-over-ranks wall time, every rank's own ms/step, and how
     many ranks' record blocks arrived intact in this rank's gathered batch (checksum of each rank's local block, gathered
     separately, against the block sums of the gathered records)."""
+    if dist.get_backend() == 'gloo':               # dry launch / one-GPU rehearsal: gloo collectives on host tensors
+        dev = torch.device('cpu')
     mine = torch.tensor([dt], dtype=torch.float64, device=dev)
     allt = torch.empty(world, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(allt, mine)
     t = mine.clone()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     multi = {'per_rank_ms_per_step': [round(v / steps * 1e3, 3) for v in allt.tolist()]}
-    cs = local.double().sum().reshape(1)
-    allcs = torch.empty(world, dtype=torch.float64, device=dev)
+    # checksum of a block = int64 sum of its fp32 bit patterns: exact and independent of the order a reduction adds in (a float sum of
+    # the (B,100,32) block and a row sum of the gathered tensor round differently: seen as ranks_seen 1 of 2 in a rehearsal)
+    cs = local.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1).to(dev)
+    allcs = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allcs, cs)
     ok = rec.shape[0] == world * B
-    blocks = rec.reshape(world, -1).double().sum(1) if ok else None
+    blocks = rec.contiguous().view(torch.int32).reshape(world, -1).to(torch.int64).sum(1).to(dev) if ok else None
     multi['ranks_seen'] = int((blocks == allcs).sum().item()) if ok else 0
     multi['gathered_shape'] = list(rec.shape)
     multi['allgather_us_last_step'] = round(gather_us, 1) if gather_us is not None else None
@@ -544,7 +549,7 @@ def main():
     launched = 'RANK' in os.environ
     if not launched and (args.gpus > 1 or args.force_launch):
         # BEFORE any GPU call: N fresh rank processes, this one only waits for them.  device_count() does not initialise HIP
-        if not args.dry_launch:
+        if not args.dry_launch and not args.rehearse_one_gpu:
             have = torch.cuda.device_count()
             if have < args.gpus:
                 raise SystemExit('bench.py: --gpus %d but this node shows %d GPUs' % (args.gpus, have))
@@ -559,6 +564,8 @@ def main():
         return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path')
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # under a launcher (RANK set) the process group is created even for one rank, so that the collective path of the
@@ -566,7 +573,10 @@ def main():
     use_dist = world > 1 or launched
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)
 
     import rtm3d_amd
     from rtm3d_amd import weights, distributed as rdist
@@ -752,6 +762,8 @@ def main():
             out['sparse_heads'] = {'patch_plan_ms': round(sum(i['ms'] for i in peak_info), 4),
                                    'patch_plan_gflop_per_batch': round(sum(i['flops'] for i in peak_info) / 1e9, 1),
                                    'ops': [{'name': i['name'], 'kernel': i['kernel'], 'ms': round(i['ms'], 4)} for i in peak_info]}
+        if args.rehearse_one_gpu:
+            out['INVALID'] = 'rehearsal: %d ranks share ONE GPU and gather over gloo through host memory; not a throughput measurement' % world
         if args.zero_weights:
             out['DIAGNOSTIC'] = 'all-zero weights: every activation is zero (not the benchmark workload)'
         if args.graph:

@@ -89,6 +89,14 @@ def all_gather_records(rec, group=None, check_shapes=False, always=False, out=No
     elif tuple(out.shape) != shape or out.dtype != rec.dtype or out.device != rec.device or not out.is_contiguous():
         raise ValueError('all_gather_records: out must be a contiguous %s %s tensor on %s, got %s %s on %s'
                          % (shape, rec.dtype, rec.device, tuple(out.shape), out.dtype, out.device))
+    if rec.is_cuda and dist.get_backend(group) == 'gloo':
+        # REHEARSAL transport only (bench.py --rehearse-one-gpu: several ranks sharing one GPU, where RCCL refuses duplicate
+        # devices): gloo has no CUDA all-gather, so the records are staged through host memory, synchronously.  The product
+        # transport is backend "nccl" (RCCL over xGMI); nothing else takes this branch.
+        host = torch.empty(shape, dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, rec, group=group)
     return out
 

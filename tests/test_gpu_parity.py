@@ -864,6 +864,29 @@ def test_bench_spawn_path_nccl_world1(dev):
     assert out['multi_gpu']['allgather_us_last_step'] > 0 and out['value'] > 0
 
 
+def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
+    """`bench.py --gpus 2 --rehearse-one-gpu`: the launcher starts TWO rank processes that both run the whole hot path on GPU 0 on
+    their own shards of the global batch (images rank * B ...) and exchange their records per step from the pipeline's side
+    stream - over gloo through host memory, because RCCL refuses two ranks on one device.  Everything of the N > 1 path but the
+    transport runs: preallocated (2B, 100, 32) gather buffers, ordering by global image index, both ranks' blocks intact in
+    rank 0's gathered batch (checksums gathered separately), per-rank timing; the line says INVALID (no throughput claim)."""
+    import subprocess, sys, os, json
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-one-gpu', '--steps', '3', '--warmup', '1',
+                        '--batch', '4', '--height', '128', '--width', '256', '--backbone', 'RESNET-18', '--no-cpu-baseline', '--no-parity',
+                        '--no-sparse-probe'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    mg = out['multi_gpu']
+    assert out['n_gpus'] == 2 and mg['ranks_seen'] == 2 and mg['gathered_shape'] == [8, 100, 32] and len(mg['per_rank_ms_per_step']) == 2
+    assert out['config']['global_batch'] == 8 and 'INVALID' in out
+
+
 def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
     """hipGraph replay of the plan (small batches) against the eager replay: same logits bit for bit, over several
     replays, fresh input/output buffers (new graph keys) and a second shape; the plan cache keeps at most MAX_PLANS."""
