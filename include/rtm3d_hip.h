@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 6
+#define RTM3D_ABI_VERSION 7
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 49
 
@@ -119,6 +119,20 @@ int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor, int out_c
  * [4][64][8] (MFMA A fragments, K = 32), fp32 biases [64] with BN folded.                                                      */
 int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv_tensor, int conv_coff, int proj_tensor, int proj_coff,
                             int w_conv_blob, int b_conv_blob, int w_proj_blob, int b_proj_blob);
+
+/* Tail of a DLA level-1 tree on 64 channels (DLA-34 level2) in one launch, three reference ops reading x1 once and never
+ * writing x2: x2 = ReLU(BN(conv3x3(in)) + x1) (tree2's BasicBlock.conv2 + residual, models/nets/dla.py:92-99), out =
+ * ReLU(BN(conv1x1(cat[x2, x1]))) (Root.forward, dla.py:233-241) and - when pool_tensor >= 0 - pool = max_pool2d(out, 2, 2)
+ * (the next level's `downsample`, dla.py:170-172,190).  in / x1 (res) / out: 64 channels at *_coff of tensors of equal
+ * shape, H % 8 == 0, W % 32 == 0, `in` with a border >= 1; pool: 64 channels at half resolution.  w_conv_blob: the
+ * kernel = 5 packing of rtm3d_op_conv ([9][2][4][64 lanes][8]); w_root_blob: fp16 [4 output tiles][4 K-steps][64 lanes][8]
+ * with lane = fk * 16 + row, element j = root weight [tile * 16 + row][s * 32 + (j >> 2) * 16 + fk * 4 + (j & 3)] over the
+ * concatenated input [x2 | x1] (the K order in which the conv's accumulator fragments are handed to the root's MFMAs);
+ * fp32 biases [64] with BN folded.  Same result as the rtm3d_op_conv / rtm3d_op_maxpool launches it replaces up to fp32
+ * summation order.                                                                                                        */
+int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,
+                         int w_conv_blob, int b_conv_blob, int w_root_blob, int b_root_blob,
+                         int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff);
 
 /* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
  * input = the nheads x 256-channel tensor written by the grouped head conv (nheads = 4, or 2 for the

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_GROUPS, MAX_TAPS = 4, 49
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -67,6 +67,7 @@ SIGNATURES = {
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
     'rtm3d_op_stem_fused': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_conv32s2_fused': (c_int, [c_void_p] + [c_int] * 10),
+    'rtm3d_op_conv64_root': (c_int, [c_void_p] + [c_int] * 14),
     'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_patch_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_gather_peak_patches': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

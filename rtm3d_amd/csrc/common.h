@@ -131,6 +131,16 @@ struct Conv32S2Args {
     int op_Hp, op_Wp, op_C, op_P, op_coff;
 };
 
+struct RootKArgs {
+    const f16* w;           // [4 output tiles][4 K-steps][64 lanes][8] MFMA A fragments of the 128 -> 64 root, K order permuted (conv64_root.hip)
+    const float* bias;      // [64]
+    f16* out;               // root output slice: 64 channels at o_coff
+    int o_Hp, o_Wp, o_C, o_P, o_coff;
+    f16* pool;              // 2x2 / stride 2 max-pool of the root output (64 channels at p_coff, half resolution), or null
+    int p_Hp, p_Wp, p_C, p_P, p_coff;
+    int relu;
+};
+
 struct PatchMaskArgs {
     f16* base;              // [n_slots][S][S][C] patch tensor (no border)
     const int32_t* yx;      // [n_slots][2] peak (y, x) in map pixels, -1 = empty slot (written by rtm3d_gather_peak_patches)
@@ -148,6 +158,7 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
 bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 bool conv64_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
+hipError_t launch_conv64_root(const ConvKArgs& a, const RootKArgs& r, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 bool conv128_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv128_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);

@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX, OP_PATCH_MASK };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV64_ROOT, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX, OP_PATCH_MASK };
 
 struct Op {
     OpKind kind;
@@ -43,6 +43,7 @@ struct Op {
     StemFusedArgs sf;
     Conv32S2Args c32;
     PatchMaskArgs pm;
+    RootKArgs root;
 };
 
 struct rtm3d_ctx {
@@ -486,6 +487,58 @@ extern "C" int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_cof
     return 0;
 }
 
+extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,
+                                    int w_conv_blob, int b_conv_blob, int w_root_blob, int b_root_blob,
+                                    int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff) {
+    Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
+    Tensor* res = ctx ? get_tensor(ctx, res_tensor) : nullptr;
+    Tensor* out = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    Tensor* pool = ctx && pool_tensor >= 0 ? get_tensor(ctx, pool_tensor) : nullptr;
+    if (!in || !res || !out || (pool_tensor >= 0 && !pool)) RT_FAIL("op_conv64_root: bad tensors");
+    if (in->P < 1 || in_coff < 0 || in_coff + 64 > in->C || (in_coff % 8)) RT_FAIL("op_conv64_root: input slice mismatch (64 channels, border >= 1)");
+    if (in->H % 8 || in->W % 32) RT_FAIL("op_conv64_root: needs H %% 8 == 0 and W %% 32 == 0 (got %dx%d)", in->H, in->W);
+    for (Tensor* t : {res, out})
+        if (t->H != in->H || t->W != in->W || t->B != in->B) RT_FAIL("op_conv64_root: residual / output shape mismatch");
+    if (res_coff < 0 || res_coff + 64 > res->C || (res_coff % 8) || out_coff < 0 || out_coff + 64 > out->C || (out_coff % 8)) RT_FAIL("op_conv64_root: residual / output slice mismatch");
+    if (res == out && res_coff < out_coff + 64 && out_coff < res_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps x1 (another workgroup may still read it)");
+    if (in == out && in_coff < out_coff + 64 && out_coff < in_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps the conv input");
+    if (pool) {
+        if (pool->H * 2 != in->H || pool->W * 2 != in->W || pool->B != in->B || pool_coff < 0 || pool_coff + 64 > pool->C || (pool_coff % 8))
+            RT_FAIL("op_conv64_root: pooled output slice mismatch (half resolution, 64 channels)");
+    }
+    size_t wc = 0, bc = 0, wr = 0, br = 0;
+    const f16* w0 = (const f16*)get_blob(ctx, w_conv_blob, &wc);
+    const float* b0 = (const float*)get_blob(ctx, b_conv_blob, &bc);
+    const f16* w1 = (const f16*)get_blob(ctx, w_root_blob, &wr);
+    const float* b1 = (const float*)get_blob(ctx, b_root_blob, &br);
+    if (!w0 || !b0 || !w1 || !b1 || wc != (size_t)9 * 64 * 64 * sizeof(f16) || bc != 64 * sizeof(float) || wr != (size_t)64 * 128 * sizeof(f16) || br != 64 * sizeof(float))
+        RT_FAIL("op_conv64_root: weight/bias blob size mismatch");
+    if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv64_root: out of ticket counters");
+    if (ensure_tile_ctr(ctx)) return 1;
+    Op op;
+    ConvKArgs& a = op.conv;
+    memset(&a, 0, sizeof(a));
+    a.in = in->base; a.wgt = w0; a.bias = b0; a.res = res->base; a.out = nullptr;
+    a.HmWm = in->H * in->W; a.Wm = in->W; a.M = in->B * a.HmWm;
+    a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_stride = 1; a.in_P = in->P; a.out_scale = 1;
+    a.res_Hp = res->Hp; a.res_Wp = res->Wp; a.res_C = res->C; a.res_P = res->P;
+    a.cin = 64; a.cout = 64; a.ntaps = 9; a.relu = conv_relu ? 1 : 0; a.cpt = 1; a.ksteps = 9; a.NT = 1;
+    for (int t = 0; t < 9; ++t) a.g[0].tap_off[t] = ((t / 3 - 1) * in->Wp + (t % 3 - 1)) * in->C;
+    a.g[0].in_coff = in_coff; a.g[0].res_coff = res_coff;
+    RootKArgs& r = op.root;
+    memset(&r, 0, sizeof(r));
+    r.w = w1; r.bias = b1; r.out = out->base; r.o_Hp = out->Hp; r.o_Wp = out->Wp; r.o_C = out->C; r.o_P = out->P; r.o_coff = out_coff;
+    r.relu = root_relu ? 1 : 0;
+    if (pool) { r.pool = pool->base; r.p_Hp = pool->Hp; r.p_Wp = pool->Wp; r.p_C = pool->C; r.p_P = pool->P; r.p_coff = pool_coff; }
+    op.kind = OP_CONV64_ROOT; op.groups = 1; op.bn_tile = 64; op.epi_nchw = 0; op.out_slot = -1; op.ticket_slot = ctx->ticket_slots_used++;
+    op.name = pool ? "conv3x3_c64+root1x1+pool_fused" : "conv3x3_c64+root1x1_fused";
+    const double M = (double)a.M;
+    op.flops = 2.0 * M * (9.0 * 64 * 64 + 128.0 * 64);
+    op.bytes = 2.0 * M * (64.0 * 3 + (pool ? 16.0 : 0.0));      // conv input, x1, root output (+ the pooled map)
+    ctx->ops.push_back(op);
+    return 0;
+}
+
 extern "C" int rtm3d_op_patch_mask(rtm3d_ctx* ctx, int tensor, int yx_blob, int img_H, int img_W, int origin) {
     Tensor* t = ctx ? get_tensor(ctx, tensor) : nullptr;
     if (!t) RT_FAIL("op_patch_mask: bad tensor");
@@ -618,6 +671,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
+        case OP_CONV64_ROOT: e = launch_conv64_root(op.conv, op.root, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV128_HALO: e = launch_conv128_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_STEM_FUSED: {
             StemFusedArgs a = op.sf;

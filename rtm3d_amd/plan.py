@@ -24,6 +24,7 @@ from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS
 
 V2_MIN_TILES = 200
 FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 stride-2 conv in one launch (conv32s2_fused.hip)
+FUSE_LEVEL_TAIL = True    # DLA level2 tail: tree2.conv2 + residual, the root 1x1 and the next level's 2x2 max-pool in one launch (conv64_root.hip)
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
@@ -568,6 +569,18 @@ def pack_conv64_weights(wt):
     return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
 
 
+def pack_root64_weights(wt):
+    """wt: (64, 128) fp32 [cout][cat channel] (cat = [x2 | x1]) -> fp16 [4 output tiles][4 K-steps][lane = fk*16 + row][8] for
+    conv64_root.hip: element j of lane (fk, row) in K-step s is cat channel s*32 + (j >> 2)*16 + fk*4 + (j & 3) - the order in
+    which a lane's two accumulator fragments (4 consecutive channels of two 16-channel tiles) line up as an MFMA B operand."""
+    out = np.zeros((4, 4, 4, 16, 8), np.float32)                       # ct, s, fk, row, j
+    for s_ in range(4):
+        for fk in range(4):
+            for j in range(8):
+                out[:, s_, fk, :, j] = wt[:, s_ * 32 + (j >> 2) * 16 + fk * 4 + (j & 3)].reshape(4, 16)
+    return np.ascontiguousarray(out).astype(np.float16).reshape(-1)
+
+
 def pack_headout_weights(ws, biases):
     """4 x (cout<=16, 256, 3, 3) -> fp16 [head][tap][chunk*2+kk][lane=fk*16+row][8], fp32 bias [head][16]."""
     G = len(ws)
@@ -600,6 +613,7 @@ class RealizedPlan(object):
         self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
         entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
+        tail = self._level_tail_chains() if FUSE_LEVEL_TAIL else {}
         skip = set()
         for k, op in enumerate(plan.ops):
             self._k = k
@@ -617,8 +631,73 @@ class RealizedPlan(object):
                 self.op_names.append(op['name'] + '+project+' + conv['name'].split('.', 2)[-1])
                 skip.update(entry[k])
                 continue
+            if k in tail:
+                root = plan.ops[tail[k][0]]
+                pool = plan.ops[tail[k][1]] if len(tail[k]) > 1 else None
+                self._op_conv64_root(op, root, pool)
+                self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else ''))
+                skip.update(tail[k])
+                continue
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
+
+    def _level_tail_chains(self):
+        """{index of a 64 -> 64 3x3 conv with a residual (conv64_halo-eligible): [index of the 1x1 128 -> 64 conv over
+        cat[that conv's output | its residual] (the tree's root; the conv's output has no other reader) (, index of a 2x2/2
+        max-pool of the root's output, when it directly follows)]}: one launch (conv64_root.hip); x2 is never written."""
+        P = self.plan
+        out = {}
+        for k, cv in enumerate(P.ops[:-1]):
+            rt = P.ops[k + 1]
+            if cv['op'] != 'conv' or not conv64_eligible(cv) or cv['res'][0] is None or cv.get('variant') is not None:
+                continue
+            x2, x1 = cv['out'][0], cv['res'][0]
+            users = [j for j, o in enumerate(P.ops) if j != k and self._reads(o, x2.tid) and self._reads_slice(o, x2)]
+            ok = (rt['op'] == 'conv' and rt['cin'] == 128 and rt['cout'] == 64 and rt['groups'] == 1 and list(rt['taps'][0]) == [(0, 0)]
+                  and rt['in_stride'] == 1 and rt['out_scale'] == 1 and rt['res'][0] is None and not rt['out_nchw'] and rt.get('variant') is None
+                  and x2.tid == x1.tid and x1.coff == x2.coff + 64 and rt['inp'][0].tid == x2.tid and rt['inp'][0].coff == x2.coff
+                  and users == [k + 1] and rt['out'][0].coff % 8 == 0
+                  and not (rt['out'][0].tid == x2.tid and rt['out'][0].coff < x2.coff + 128 and x2.coff < rt['out'][0].coff + 64)
+                  and rt['out'][0].tid != cv['inp'][0].tid
+                  and not any(n.tid == x2.tid and n.coff < x2.coff + 64 and x2.coff < n.coff + n.C for n in P.named.values()))
+            if not ok:
+                continue
+            chain = [k + 1]
+            if k + 2 < len(P.ops):
+                m = P.ops[k + 2]
+                ro = rt['out'][0]
+                if (m['op'] == 'maxpool' and m['k'] == 2 and m['stride'] == 2 and m['pad'] == 0 and m['inp'].tid == ro.tid
+                        and m['inp'].coff == ro.coff and m['inp'].C == 64 and m['out'].coff % 8 == 0 and m['out'].tid != ro.tid):
+                    chain.append(k + 2)
+            out[k] = chain
+        return out
+
+    @staticmethod
+    def _reads_slice(op, s):
+        """Does `op` read any channel of Slice s (same tensor)?"""
+        def hit(t, C):
+            return t is not None and t.tid == s.tid and t.coff < s.coff + s.C and s.coff < t.coff + C
+        if op['op'] == 'conv':
+            return any(hit(i, op['cin']) for i in op['inp']) or any(hit(r_, op['cout']) for r_ in op['res'])
+        if op['op'] in ('maxpool', 'headout'):
+            return hit(op['inp'], op['inp'].C)
+        if op['op'] == 'patch_mask':
+            return hit(op['t'], op['t'].C)
+        if op['op'] == 'softmax':
+            return hit(op['z_in'], op['z_in'].C) or any(hit(u, u.C) for u in op['us'])
+        return False
+
+    def _op_conv64_root(self, cv, rt, pool):
+        f32 = lambda v: self._blob(np.ascontiguousarray(v, np.float32))
+        x, x1, ro = cv['inp'][0], cv['res'][0], rt['out'][0]
+        po = pool['out'] if pool is not None else None
+        wc = self._packed(cv, 0, 'c64', 0, lambda: pack_conv64_weights(cv['w'][0]))
+        wr = self._packed(rt, 0, 'root64', 0, lambda: pack_root64_weights(rt['w'][0][0]))
+        _lib.check(self.lib.rtm3d_op_conv64_root(self.ctx, self.tids[x.tid], x.coff, self.tids[x1.tid], x1.coff, 1 if cv['relu'] else 0,
+                                                 self._blob(wc), f32(cv['bias'][0]), self._blob(wr), f32(rt['bias'][0]),
+                                                 self.tids[ro.tid], ro.coff, 1 if rt['relu'] else 0,
+                                                 self.tids[po.tid] if po is not None else -1, po.coff if po is not None else 0),
+                   'op_conv64_root')
 
     def _stem_fusion_pairs(self):
         """{index of the 7x7 NHWC4 stem conv: [index of the 3x3 16->16 conv that is its only consumer (, index of the 3x3

@@ -411,6 +411,61 @@ def test_fused_level_entry_vs_torch(shape):
         np.testing.assert_allclose(res[fuse][1], ref_m, rtol=3e-3, atol=3e-3 * max(1.0, np.abs(ref_m).max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 64, True), (1, 8, 32, True), (3, 40, 96, False), (4, 96, 320, True)])
+def test_fused_level_tail_vs_torch(shape):
+    """conv64_root.hip: 3x3 64->64 conv + residual + ReLU, the tree's 1x1 root over cat[x2, x1] (ReLU) and the next level's 2x2
+    max-pool in one launch (DLA level2 tail), against plain PyTorch fp32 on fp16-rounded operands and against the three-launch
+    path (x2 is only written by the latter)."""
+    B, H, W, with_pool = shape
+    rng = np.random.default_rng(B * 13 + H)
+    wc = (rng.standard_normal((64, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32); bc = rng.standard_normal(64).astype(np.float32) * 0.3
+    wr = (rng.standard_normal((64, 128, 1, 1)) / np.sqrt(128)).astype(np.float32); br = rng.standard_normal(64).astype(np.float32) * 0.3
+    t = np.abs(rng.standard_normal((B, 64, H, W))).astype(np.float32)
+    x1 = np.abs(rng.standard_normal((B, 64, H, W))).astype(np.float32)
+
+    def build():
+        P = plan_mod.Plan(B, H * 4, W * 4)
+        tt = P.tensor(H, W, 64 + 8, 1)
+        ts = P.sub(tt, 8, 64)
+        cat = P.tensor(H, W, 128, 1)
+        x2s, x1s = P.sub(cat, 0, 64), P.sub(cat, 64, 64)
+        P.conv(ts, x2s, wc, bc, relu=True, res=x1s, name='level2.tree2.conv2')
+        ot = P.tensor(H, W, 64 + 16, 1)
+        out = P.sub(ot, 16, 64)
+        P.conv(cat, out, wr, br, relu=True, name='level2.root')
+        pooled = None
+        if with_pool:
+            pt = P.tensor(H // 2, W // 2, 64 + 24, 1)
+            pooled = P.sub(pt, 24, 64)
+            P.maxpool(out, pooled, 2, 2, 0, name='level3.downsample')
+        return P, ts, x1s, out, pooled
+
+    res = {}
+    for fuse in (True, False):
+        plan_mod.FUSE_LEVEL_TAIL = fuse
+        try:
+            P, ts, x1s, out, pooled = build()
+            R = plan_mod.RealizedPlan(P, 0)
+            assert len(R.op_names) == (1 if fuse else (3 if with_pool else 2)), R.op_names
+            if fuse:
+                assert R.kernel_names()[0].startswith('conv3x3_c64+root1x1'), R.kernel_names()
+            R.close()
+            got, _ = _run(P, [(ts, t), (x1s, x1)], [out] + ([pooled] if with_pool else []))
+            res[fuse] = got
+        finally:
+            plan_mod.FUSE_LEVEL_TAIL = True
+    th, x1h = h(torch.from_numpy(t)), h(torch.from_numpy(x1))
+    x2 = h((F.conv2d(th, h(torch.from_numpy(wc)), torch.from_numpy(bc), 1, 1) + x1h).relu())
+    ref_o = h(F.conv2d(torch.cat([x2, x1h], 1), h(torch.from_numpy(wr)), torch.from_numpy(br)).relu())
+    tol = 4e-3 * max(1.0, float(ref_o.abs().max()))
+    for fuse in (True, False):
+        np.testing.assert_allclose(res[fuse][0], ref_o.numpy(), rtol=4e-3, atol=tol)
+        if with_pool:
+            # the pooled map is the exact 2x2 max of the kernel's OWN fp16 output
+            np.testing.assert_array_equal(res[fuse][1], F.max_pool2d(torch.from_numpy(res[fuse][0]), 2, 2).numpy())
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=4e-3, atol=tol)
+
+
 def test_forward_on_two_streams_is_serialised():
     """one context = one activation workspace and one set of ticket counters.  Two replays issued back to back on
     DIFFERENT streams must not overlap on the device: rtm3d_forward orders a call on a new stream behind the previous replay."""
