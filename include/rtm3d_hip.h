@@ -32,7 +32,7 @@ extern "C" {
 
 #define RTM3D_ABI_VERSION 7
 #define RTM3D_MAX_GROUPS 4
-#define RTM3D_MAX_TAPS 49
+#define RTM3D_MAX_TAPS 80
 
 typedef struct rtm3d_ctx rtm3d_ctx;
 
@@ -72,7 +72,11 @@ int rtm3d_op_input_nhwc4(rtm3d_ctx* ctx, int out_tensor);
  * "concat" never materialises: producers write slices), grouped head convs, and the four
  * sub-pixel phases of ConvTranspose2d(k4,s2,p1) (models/nets/module.py:7-15).
  * Iteration domain: m in [0, B*Hm*Wm) -> (n, y, x).
- *   input  pixel (n, y*in_stride + tap_dy[g][t], x*in_stride + tap_dx[g][t])   (unpadded coords)
+ *   input  pixel (n, y*in_stride + tap_dy[g][t], x*in_stride + tap_dx[g][t])   (unpadded coords),
+ *          channels [in_coff[g] + tap_dc[g][t], ... + cin) of the input tensor (tap_dc = 0 for an ordinary convolution;
+ *          a tap may name another channel slice of the same tensor: a DLA block's `project` 1x1 on the pooled map
+ *          (models/nets/dla.py:175-198) becomes extra K-steps of the block's second conv instead of a residual, with the
+ *          conv's own taps split into 64-channel pseudo-taps so that every tap carries cin = 64 channels)
  *   output pixel (n, y*out_scale + out_oy[g],    x*out_scale + out_ox[g])
  * Epilogue: + bias[cout] (BN folded) [+ residual at the output pixel] [ReLU] -> fp16 NHWC,
  * or (out_nchw_f32 != 0) fp32 NCHW into the caller buffer given to rtm3d_forward.                */
@@ -85,6 +89,7 @@ typedef struct rtm3d_conv_desc {
     int in_coff[RTM3D_MAX_GROUPS], out_coff[RTM3D_MAX_GROUPS], res_coff[RTM3D_MAX_GROUPS];
     int out_oy[RTM3D_MAX_GROUPS], out_ox[RTM3D_MAX_GROUPS];
     int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
+    int tap_dc[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS]; /* channel offset of the tap relative to in_coff (multiple of 8; kernels 0 and 2 only) */
     int relu;
     int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
     int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 2 = MFMA 256x256 tile

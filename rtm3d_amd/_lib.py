@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
 ABI_VERSION = 7
-MAX_GROUPS, MAX_TAPS = 4, 49
+MAX_GROUPS, MAX_TAPS = 4, 80
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
 c_double = ctypes.c_double
@@ -26,6 +26,7 @@ class ConvDesc(ctypes.Structure):
         ('in_coff', c_int * MAX_GROUPS), ('out_coff', c_int * MAX_GROUPS), ('res_coff', c_int * MAX_GROUPS),
         ('out_oy', c_int * MAX_GROUPS), ('out_ox', c_int * MAX_GROUPS),
         ('tap_dy', (c_int * MAX_TAPS) * MAX_GROUPS), ('tap_dx', (c_int * MAX_TAPS) * MAX_GROUPS),
+        ('tap_dc', (c_int * MAX_TAPS) * MAX_GROUPS),
         ('relu', c_int),
         ('w_blob', c_int), ('bias_blob', c_int),
         ('kernel', c_int), ('bn_tile', c_int),

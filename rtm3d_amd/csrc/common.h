@@ -21,7 +21,7 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
 
 
 #define RT_MAX_GROUPS 4
-#define RT_MAX_TAPS 49
+#define RT_MAX_TAPS 80
 
 // Geometry of one padded NHWC fp16 activation tensor as the kernels see it.
 struct TensorView {
@@ -34,7 +34,7 @@ struct ConvGroupArgs {
     int out_oy, out_ox;
     uint32_t w_off;          // element offset of this group's packed weights
     int bias_off;            // element offset into bias
-    int tap_off[RT_MAX_TAPS];  // (dy*in_Wp + dx)*in_C, elements (may be negative)
+    int tap_off[RT_MAX_TAPS];  // (dy*in_Wp + dx)*in_C + tap_dc, elements (may be negative)
 };
 
 struct ConvKArgs {

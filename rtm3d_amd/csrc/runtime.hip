@@ -251,7 +251,10 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
             const int ylo = dy, yhi = (d->Hm - 1) * d->in_stride + dy, xlo = dx, xhi = (d->Wm - 1) * d->in_stride + dx;
             if (ylo < -in->P || xlo < -in->P || yhi >= in->H + in->P || xhi >= in->W + in->P)
                 RT_FAIL("op_conv: tap (%d,%d) leaves the padded input (H=%d W=%d pad=%d, Hm=%d Wm=%d stride=%d)", dy, dx, in->H, in->W, in->P, d->Hm, d->Wm, d->in_stride);
-            a.g[g].tap_off[t] = (dy * in->Wp + dx) * in->C;
+            const int dc = d->tap_dc[g][t];
+            if (dc && d->kernel != 0 && d->kernel != 2) RT_FAIL("op_conv: per-tap channel offsets need kernel 0 or 2");
+            if ((dc % 8) || d->in_coff[g] + dc < 0 || d->in_coff[g] + dc + d->cin > in->C) RT_FAIL("op_conv: tap %d names channels [%d, %d) outside the %d-channel input tensor", t, d->in_coff[g] + dc, d->in_coff[g] + dc + d->cin, in->C);
+            a.g[g].tap_off[t] = (dy * in->Wp + dx) * in->C + dc;
         }
         if (d->in_coff[g] < 0 || d->in_coff[g] + d->cin > in->C || (d->in_coff[g] % 8)) RT_FAIL("op_conv: input channel slice out of range");
         const int oyhi = (d->Hm - 1) * d->out_scale + d->out_oy[g], oxhi = (d->Wm - 1) * d->out_scale + d->out_ox[g];

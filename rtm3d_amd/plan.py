@@ -16,6 +16,7 @@ Graph sources: models/nets/dla.py:186-210,322-332 (DLA-34 trees), models/nets/re
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -25,6 +26,8 @@ from .weights import parse_backbone, DLA34_CHANNELS, DLA34_LEVELS, RESNET_BLOCKS
 V2_MIN_TILES = 200
 FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 stride-2 conv in one launch (conv32s2_fused.hip)
 FUSE_LEVEL_TAIL = True    # DLA level2 tail: tree2.conv2 + residual, the root 1x1 and the next level's 2x2 max-pool in one launch (conv64_root.hip)
+FOLD_PROJECT = True       # DLA levels 3-5: a block's `project` 1x1 (on the pooled input) as extra K-steps of the block's second conv
+FOLD_PROJECT_C128 = os.environ.get('RTM3D_FOLD_C128', '1') != '0'  # ... also where that conv would otherwise take conv128_halo (level3), which has no one-tap chunk: generic kernel
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
@@ -205,10 +208,11 @@ def _fold_bn(sd, conv, bn=None):
     return w.astype(np.float32), b.astype(np.float32)
 
 
-def _dla_block(P, sd, p, x, out, stride, residual, mid_name=None):
+def _dla_block(P, sd, p, x, out, stride, residual, mid=None):
     """BasicBlock (models/nets/dla.py:86-100): relu(bn2(conv2(relu(bn1(conv1 x)))) + residual)."""
     Ho, Wo = P.dims(out)
-    mid = P.tensor(Ho, Wo, out.C, 1, name=mid_name)
+    if mid is None:
+        mid = P.tensor(Ho, Wo, out.C, 1)
     w, b = fold_bn(sd, p + '.conv1', p + '.norm1')
     P.conv(x, mid, w, b, stride=stride, relu=True, name=p + '.conv1')
     w, b = fold_bn(sd, p + '.conv2', p + '.norm2')
@@ -227,7 +231,7 @@ def _dla_tree1(P, sd, p, x, bottom, cat, cin, cout, stride, extra):
     else:
         resid = bottom
     x2s, x1s = P.sub(cat, 0, cout), P.sub(cat, cout, cout)
-    _dla_block(P, sd, p + '.tree1', x, x1s, stride, resid)
+    _dla_block(P, sd, p + '.tree1', x, x1s, stride, resid, mid=extra.get('mid'))
     _dla_block(P, sd, p + '.tree2', x1s, x2s, 1, x1s)
     w, b = fold_bn(sd, p + '.root.conv', p + '.root.norm')
     P.conv(cat, extra['out'], w, b, relu=True, name=p + '.root')
@@ -253,22 +257,28 @@ def _build_dla(P, sd, H, W, feat_out):
         out = feat_out[i - 2]
         if DLA34_LEVELS[i] == 1:
             level_root = i > 2
-            cat = P.tensor(Ho, Wo, 2 * cout + (cin if level_root else 0), 1)
+            # (level_root: the first block's intermediate map lives in the tensor that holds the pooled input, so that the block's
+            # `project` 1x1 can run as extra K-steps of its second conv: RealizedPlan._project_folds)
+            cat = P.tensor(Ho, Wo, 2 * cout + ((cin + cout) if level_root else 0), 1)
+            mid = None
             if level_root:
                 bottom = P.sub(cat, 2 * cout, cin)
+                mid = P.sub(cat, 2 * cout + cin, cout)
             else:
                 bottom = P.tensor(Ho, Wo, cin, 0)
             P.maxpool(x, bottom, 2, 2, 0, name=p + '.downsample')
-            _dla_tree1(P, sd, p, x, bottom, cat, cin, cout, 2, {'out': out})
+            _dla_tree1(P, sd, p, x, bottom, P.sub(cat, 0, 2 * cout + (cin if level_root else 0)), cin, cout, 2, {'out': out, 'mid': mid})
         else:
             # level-2 tree with level_root: final root input = [x2' | x1' | bottom | x1_outer]
-            cat2 = P.tensor(Ho, Wo, 3 * cout + cin, 1)
+            cat2t = P.tensor(Ho, Wo, 4 * cout + cin, 1)          # [x2' | x1' | bottom | x1_outer] + tree1.tree1's intermediate map
+            cat2 = P.sub(cat2t, 0, 3 * cout + cin)
             bottom = P.sub(cat2, 2 * cout, cin)
             x1_outer = P.sub(cat2, 2 * cout + cin, cout)
+            mid = P.sub(cat2t, 3 * cout + cin, cout)
             P.maxpool(x, bottom, 2, 2, 0, name=p + '.downsample')
             # (the outer tree's own `project` output is never consumed: models/nets/dla.py:195-202)
             cat1 = P.tensor(Ho, Wo, 2 * cout, 1)
-            _dla_tree1(P, sd, p + '.tree1', x, bottom, cat1, cin, cout, 2, {'out': x1_outer})
+            _dla_tree1(P, sd, p + '.tree1', x, bottom, cat1, cin, cout, 2, {'out': x1_outer, 'mid': mid})
             _dla_tree1(P, sd, p + '.tree2', x1_outer, x1_outer, cat2, cout, cout, 1, {'out': out})
         x = out
 
@@ -614,7 +624,11 @@ class RealizedPlan(object):
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
         entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
         tail = self._level_tail_chains() if FUSE_LEVEL_TAIL else {}
-        skip = set()
+        folds = self._project_folds() if FOLD_PROJECT else {}
+        skip = set(folds.values())
+        folded_by = {}
+        for c2k, pjk in folds.items():
+            folded_by[c2k] = self._folded_conv(plan.ops[c2k], plan.ops[pjk])
         for k, op in enumerate(plan.ops):
             self._k = k
             if k in skip:
@@ -638,8 +652,60 @@ class RealizedPlan(object):
                 self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else ''))
                 skip.update(tail[k])
                 continue
+            if k in folded_by:
+                op = folded_by[k]
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
+
+    def _project_folds(self):
+        """{index of a block's second conv: index of the `project` 1x1 that produces its residual} where the 1x1 (no ReLU, stride
+        1, a multiple of 64 input channels) reads another channel slice of the tensor the conv reads, and nothing else reads its
+        output: conv(t) + bias + project(b) is ONE convolution over [t | b] whose extra taps are the centre pixel of b
+        (models/nets/dla.py:92-99,190-198: out = bn2(conv2(.)) + project(bottom), then ReLU).  Exact in real arithmetic; in fp16
+        storage it saves the rounding of the projected map.  The 1x1 launch, its output tensor and the residual read go away."""
+        P = self.plan
+        out = {}
+        for k, c2 in enumerate(P.ops):
+            if (c2['op'] != 'conv' or c2['groups'] != 1 or c2['res'][0] is None or c2['in_stride'] != 1 or c2['out_scale'] != 1
+                    or c2['out_nchw'] or c2['cin'] % 64 or c2.get('variant') is not None or 'tap_dc' in c2):
+                continue
+            R = c2['res'][0]
+            prods = [j for j in range(k) if P.ops[j]['op'] == 'conv' and any(o is not None and o.tid == R.tid for o in P.ops[j]['out'])]
+            if len(prods) != 1:
+                continue
+            pj = P.ops[prods[0]]
+            users = [j for j, o in enumerate(P.ops) if j != prods[0] and self._reads(o, R.tid)]
+            ok = (pj['groups'] == 1 and list(pj['taps'][0]) == [(0, 0)] and pj['in_stride'] == 1 and pj['out_scale'] == 1 and not pj['relu']
+                  and pj['res'][0] is None and not pj['out_nchw'] and pj['cin'] % 64 == 0 and pj['cout'] == c2['cout']
+                  and pj['out'][0].coff == R.coff and pj['out'][0].C == R.C and pj.get('variant') is None and users == [k]
+                  and pj['inp'][0].tid == c2['inp'][0].tid and (pj['Hm'], pj['Wm']) == (c2['Hm'], c2['Wm'])
+                  and len(c2['taps'][0]) * (c2['cin'] // 64) + pj['cin'] // 64 <= _lib.MAX_TAPS
+                  and not any(n.tid == R.tid for n in P.named.values()))
+            if ok and not FOLD_PROJECT_C128 and USE_CONV128 and conv128_eligible(c2, P.B):
+                ok = False
+            if ok and conv64_eligible(c2):
+                ok = False                      # (the register-resident 64-channel kernel has no generic taps)
+            if ok:
+                out[k] = prods[0]
+        return out
+
+    @staticmethod
+    def _folded_conv(c2, pj):
+        cout, cpt, e = c2['cout'], c2['cin'] // 64, pj['cin'] // 64
+        taps, w2, wp = c2['taps'][0], c2['w'][0], pj['w'][0][0]              # w2: (taps, cout, cin), wp: (cout, cin_b)
+        wt = np.zeros((len(taps) * cpt + e, cout, 64), np.float32)
+        tl, dc = [], []
+        for t, (dy, dx) in enumerate(taps):
+            for q in range(cpt):
+                wt[t * cpt + q] = w2[t][:, q * 64:(q + 1) * 64]
+                tl.append((dy, dx)); dc.append(q * 64)
+        delta = pj['inp'][0].coff - c2['inp'][0].coff
+        for q in range(e):
+            wt[len(taps) * cpt + q] = wp[:, q * 64:(q + 1) * 64]
+            tl.append((0, 0)); dc.append(delta + q * 64)
+        op = dict(c2)
+        op.update(cin=64, taps=[tl], tap_dc=[dc], w=wt[None], bias=c2['bias'] + pj['bias'], res=[None], name=c2['name'] + '+project')
+        return op
 
     def _level_tail_chains(self):
         """{index of a 64 -> 64 3x3 conv with a residual (conv64_halo-eligible): [index of the 1x1 128 -> 64 conv over
@@ -865,6 +931,7 @@ class RealizedPlan(object):
             d.out_oy[g], d.out_ox[g] = op['out_off'][g]
             for t, (dy, dx) in enumerate(op['taps'][g]):
                 d.tap_dy[g][t], d.tap_dx[g][t] = dy, dx
+                d.tap_dc[g][t] = op['tap_dc'][g][t] if 'tap_dc' in op else 0
         d.relu = 1 if op['relu'] else 0
         d.softmax_stat_slot = self._stat_slots.get(self._k, -1)
         d.out_nchw_f32 = op['out_nchw']

@@ -466,6 +466,48 @@ def test_fused_level_tail_vs_torch(shape):
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=4e-3, atol=tol)
 
 
+@pytest.mark.parametrize('case', [(2, 24, 80, 128, 256, 64), (1, 12, 40, 256, 512, 0), (8, 48, 160, 64, 128, 0), (32, 24, 80, 128, 256, 0), (1, 6, 10, 256, 512, 64)])
+def test_project_fold_vs_torch(case):
+    """RealizedPlan._project_folds: a DLA block's `project` 1x1 (on the pooled input, another channel slice of the tensor the
+    block's second conv reads) as extra K-steps of that conv (rtm3d_conv_desc.tap_dc) instead of a launch + residual read:
+    against plain PyTorch fp32 on fp16-rounded operands and against the two-launch path, on the 128-pixel kernel (incl. its
+    small-launch split-K form) and the persistent 256-pixel one."""
+    B, H, W, cb, cout, lead = case
+    rng = np.random.default_rng(B * 17 + H)
+    w2 = (rng.standard_normal((cout, cout, 3, 3)) / np.sqrt(cout * 9)).astype(np.float32); b2 = rng.standard_normal(cout).astype(np.float32) * 0.3
+    wp = (rng.standard_normal((cout, cb, 1, 1)) / np.sqrt(cb)).astype(np.float32); bp = rng.standard_normal(cout).astype(np.float32) * 0.3
+    t = np.abs(rng.standard_normal((B, cout, H, W))).astype(np.float32)
+    bot = np.abs(rng.standard_normal((B, cb, H, W))).astype(np.float32)
+
+    def build():
+        P = plan_mod.Plan(B, H * 8, W * 8)
+        big = P.tensor(H, W, lead + cb + cout, 1)
+        bs, ms = P.sub(big, lead, cb), P.sub(big, lead + cb, cout)
+        resid = P.tensor(H, W, cout, 0)
+        P.conv(bs, resid, wp, bp, name='lvl.project')
+        ot = P.tensor(H, W, cout, 1)
+        P.conv(ms, ot, w2, b2, relu=True, res=resid, name='lvl.tree1.conv2')
+        return P, bs, ms, ot
+
+    res = {}
+    for fold in (True, False):
+        plan_mod.FOLD_PROJECT = fold
+        try:
+            P, bs, ms, ot = build()
+            R = plan_mod.RealizedPlan(P, 0)
+            assert len(R.op_names) == (1 if fold else 2), R.op_names
+            R.close()
+            (o,), _ = _run(P, [(bs, bot), (ms, t)], [ot])
+            res[fold] = o
+        finally:
+            plan_mod.FOLD_PROJECT = True
+    th, bh = h(torch.from_numpy(t)), h(torch.from_numpy(bot))
+    ref = (F.conv2d(th, h(torch.from_numpy(w2)), torch.from_numpy(b2), 1, 1) + F.conv2d(bh, h(torch.from_numpy(wp)), torch.from_numpy(bp))).relu()
+    tol = 4e-3 * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(res[True], h(ref).numpy(), rtol=4e-3, atol=tol)
+    np.testing.assert_allclose(res[False], h(ref).numpy(), rtol=4e-3, atol=2 * tol)       # (this path also rounds the projected map to fp16)
+
+
 def test_forward_on_two_streams_is_serialised():
     """one context = one activation workspace and one set of ticket counters.  Two replays issued back to back on
     DIFFERENT streams must not overlap on the device: rtm3d_forward orders a call on a new stream behind the previous replay."""
