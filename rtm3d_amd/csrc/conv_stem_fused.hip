@@ -20,6 +20,9 @@
 #include "common.h"
 #include "../../include/rtm3d_hip.h"
 
+// ReLU on the packed fp16 result (2 v_pk_max_f16 instead of 4 canonicalising + 4 clamping v_max_f32 per fragment; same values:
+// max commutes with rounding)
+#define SF_RELU4(acc) __builtin_elementwise_max((f16x4){(f16)(acc)[0], (f16)(acc)[1], (f16)(acc)[2], (f16)(acc)[3]}, (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f})
 #define SF_TH 16
 #define SF_TW 32
 
@@ -53,7 +56,13 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
     // initial values, tap offsets computed once per lane.  The 43 % LDS bank-conflict share of the profile is the 8-byte stores of
     // the two 16-channel maps (16 lanes, 32-byte pixel stride: 4-way); a 16-byte half swap keyed on bit 2 of the pixel index makes
     // them 2-way and keeps the ds_read_b128 operand reads conflict-free, at three more VALU instructions per operand read - measured
-    // on one box: 0.309 -> 0.341 ms.  The conflicts are not what the kernel waits for; the swap is not in.)
+    // on one box: 0.309 -> 0.341 ms.  The conflicts are not what the kernel waits for; the swap is not in.
+    // Round 4, same-box A/Bs: ReLU as v_pk_max_f16 on the converted pair instead of fmaxf on the fp32 values (which costs a
+    // canonicalising v_max per element on top of the clamp: 8 instructions per fragment against 2) 0.300 -> 0.287 ms; two
+    // fragments per step in stage 3 (two independent MFMA chains, operand reads of one under the multiplies of the other)
+    // 0.288 vs 0.287; both 16-column strips per wave in stage 2 (+28 registers: spills at four waves per SIMD) 0.355; the stage-3
+    // loop fully unrolled 0.301 vs 0.300; three instead of four waves per SIMD allowed 0.300.  Time follows the instruction
+    // count (~4 cycles per vector instruction + 16 per MFMA of a wave and tile), not latency.)
     const bool x_edge = (y0 - XO < 0) | (y0 - XO + XH > a.H) | (x0 - XO < 0) | (x0 - XO + XW > a.W);
     const bool b_edge = (y0 - BO < 0) | (y0 - BO + BH > a.H) | (x0 - BO < 0) | (x0 - BO + BW > a.W);
 
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
 
     // ---- 2. base_layer on the BH x BW halo (accumulators start at the bias)
     auto base_store = [&](const f32x4& acc, int r, int c) {
-        f16x4 h = {(f16)fmaxf(acc[0], 0.f), (f16)fmaxf(acc[1], 0.f), (f16)fmaxf(acc[2], 0.f), (f16)fmaxf(acc[3], 0.f)};
+        f16x4 h = SF_RELU4(acc);
         if (b_edge) {
             const int gy = y0 - BO + r, gx = x0 - BO + c;
             if (!(gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
             f32x4 acc = bl;
 #pragma unroll
             for (int s = 0; s < 5; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], *(const f16x8*)(bp + toff[s]), acc, 0, 0, 0);
-            f16x4 h = {(f16)fmaxf(acc[0], 0.f), (f16)fmaxf(acc[1], 0.f), (f16)fmaxf(acc[2], 0.f), (f16)fmaxf(acc[3], 0.f)};
+            f16x4 h = SF_RELU4(acc);
             if (L1) {
                 if (tl_edge) {
                     const int gy = y0 - L1 + row, gx = x0 - L1 + col;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
             uint32_t u[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const f16x4 h = {(f16)fmaxf(acc[c][0], 0.f), (f16)fmaxf(acc[c][1], 0.f), (f16)fmaxf(acc[c][2], 0.f), (f16)fmaxf(acc[c][3], 0.f)};
+                const f16x4 h = SF_RELU4(acc[c]);
                 __builtin_memcpy(u[c], &h, 8);
             }
             // rows (16-lane groups) 1,3 of the c = 0 registers <-> rows 0,2 of the c = 1 registers: 8 consecutive channels per lane
