@@ -133,11 +133,16 @@ def decode3d_to_arrays(dets, K, prefix, out):
 # detections whose scores spread over 0.4 .. 0.95 (random features alone give a narrow band of peak heights)
 E2E_CASES = [('DLA-34', 1, -16.9, 3.5, 2, 128, 256, 'small'), ('RESNET-18', 1, -22.8, 6.0, 2, 128, 256, 'small'),
              ('RESNET-34', 1, -14.3, 4.0, 2, 128, 256, 'small'),
-             ('DLA-34', 1, -25.0, 4.5, 1, 384, 1280, 'full'), ('RESNET-18', 1, -30.0, 6.5, 1, 384, 1280, 'full')]
+             ('DLA-34', 1, -25.0, 4.5, 1, 384, 1280, 'full'), ('RESNET-18', 1, -30.0, 6.5, 1, 384, 1280, 'full'),
+             # the real-KITTI letterbox shape: with IS_RECT the reference pads 1242 x 375 images to 1280 x 416 (datasets/dataset_reader.py:55-61):
+             # level4 / level5 maps of 26 x 80 / 13 x 40 (H % 8 != 0 there: the 8 x 32 halo-tile kernels are not eligible)
+             ('DLA-34', 1, -25.0, 4.5, 1, 416, 1280, 'kitti416'), ('RESNET-18', 1, -29.2, 6.5, 1, 416, 1280, 'kitti416')]
 
 
-def gen_e2e():
+def gen_e2e(only_tag=None):
     for bb, seed, hb, hg, B, H, W, tag in E2E_CASES:
+        if only_tag is not None and tag != only_tag:
+            continue
         sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb, heat_gain=hg)
         m = ref_model(bb, sd)
         x = weights.synth_images(B, H, W, seed=1234)
@@ -269,13 +274,74 @@ def gen_decode3d():
     assert pl.get_field('dimension').shape == (0, 3) and pl.get_field('K').shape == (0, 9)
 
 
+# ---- a large solver fixture: >= 1500 objects through SciPy with the reference's own aimFun / jac
+LARGE_NOISE = [(0.0, 256), (0.01, 384), (0.03, 256), (0.1, 256), (0.3, 256), (2.0, 128)]      # (pixel noise sigma, objects)
+
+
+def _large_chunk(args):
+    """Worker: the reference's optim_decode_bbox3d on a chunk + the raw optimiser state of every object."""
+    clses, uvs, K = args
+    from oracle.decode3d_ref import COR
+    K33 = K.reshape(3, 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pl = ref_mu.optim_decode_bbox3d(clses, uvs, K.copy(), DIM_REF, list(REF_LOC))
+        x, fun, nit = [], [], []
+        for cls, UV in zip(clses, uvs):
+            dim = DIM_REF[cls]
+            X0 = np.array([0, 1] + [dim[2], dim[0], dim[1]] + REF_LOC)
+            res = minimize(ref_mu.aimFun(*(COR, K33, UV.T)), X0, method='L-BFGS-B', jac=ref_mu.jac(*(COR, K33, UV.T)), options=OPTIONS)
+            x.append(res.x); fun.append(res.fun); nit.append(res.nit)
+    return (np.array(pl.get_field('class'), np.int64), np.asarray(pl.get_field('Ry'), np.float64),
+            np.asarray(pl.get_field('dimension'), np.float64).reshape(-1, 3), np.asarray(pl.get_field('location'), np.float64).reshape(-1, 3),
+            np.array(x), np.array(fun), np.array(nit))
+
+
+def gen_decode3d_large():
+    """1536 synthetic cuboids (exact projections + pixel noise of six levels, fp32 key points as the model hands them over) through
+    the reference's optim_decode_bbox3d and, object by object, through SciPy with the reference's aimFun / jac (raw x, fun, nit):
+    pins the TAIL of the device solvers (tests/test_gpu_parity.py::test_decode3d_large_fixture_*)."""
+    import multiprocessing as mp
+    from oracle.decode3d_ref import project_box
+    rng = np.random.Generator(np.random.PCG64(4041))
+    K = weights.synth_intrinsics()
+    clses, uvs, noise_tag = [], [], []
+    for noise, count in LARGE_NOISE:
+        for _ in range(count):
+            cls = int(rng.integers(0, 3))
+            dim = np.array(DIM_REF[cls]) * rng.uniform(0.8, 1.25, 3)
+            loc = np.array([rng.uniform(-12, 12), rng.uniform(0.5, 1.6), rng.uniform(6, 55)])
+            ry = rng.uniform(-np.pi, np.pi)
+            uv = project_box(dim, loc, ry, K) + noise * rng.standard_normal((8, 2))
+            clses.append(cls); uvs.append(uv.astype(np.float32)); noise_tag.append(noise)
+    clses, uvs = np.array(clses, np.int64), np.stack(uvs)
+    n, step = len(clses), 64
+    chunks = [(clses[i:i + step], uvs[i:i + step], K) for i in range(0, n, step)]
+    with mp.get_context('fork').Pool(8) as pool:
+        parts = pool.map(_large_chunk, chunks)
+    out = {'clses': clses, 'uv': uvs, 'K': K, 'dim_ref': np.array(DIM_REF), 'ref_loc': np.array(REF_LOC, np.float64), 'noise': np.array(noise_tag),
+           'out_class': np.concatenate([p[0] for p in parts]), 'out_Ry': np.concatenate([p[1] for p in parts]),
+           'out_dimension': np.concatenate([p[2] for p in parts]), 'out_location': np.concatenate([p[3] for p in parts]),
+           'raw_x': np.concatenate([p[4] for p in parts]), 'raw_fun': np.concatenate([p[5] for p in parts]), 'raw_nit': np.concatenate([p[6] for p in parts])}
+    kept = out['raw_fun'] < 0.1
+    assert kept.sum() == len(out['out_class'])
+    np.savez_compressed(os.path.join(HERE, 'decode3d_large.npz'), **out)
+    print('decode3d_large: %d objects, kept %d, nit %d..%d; kept per noise level %s' % (
+        n, kept.sum(), out['raw_nit'].min(), out['raw_nit'].max(), {nz: int(kept[out['noise'] == nz].sum()) for nz, _ in LARGE_NOISE}))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['e2e', 'planted', 'decode2d', 'decode3d']
     if 'decode3d' in which:
         gen_decode3d()
+    if 'decode3d_large' in which:
+        gen_decode3d_large()
     if 'decode2d' in which:
         gen_decode2d()
     if 'e2e' in which:
         gen_e2e()
+    for w in which:
+        if w.startswith('e2e:'):
+            gen_e2e(w.split(':', 1)[1])                 # only the cases of one tag, e.g. e2e:kitti416
     if 'planted' in which:
         gen_planted()

@@ -7,6 +7,8 @@ fp32 accumulation) within 2 x the measured error of the fp32 reference (LOGIT_RT
 verification mode within 2e-5 of scale, identical detections."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,13 @@ from tests.util import load_golden, dets_from_golden, canon_dets, to_np, record_
 LOGIT_RTOL = 0.010
 Z_RTOL = 0.009
 FEAT_RTOL = 0.003
+# Full-size maps (round 4): the fused map z = z0 + sum u * softmax_HW(u) has isolated pixels where a PEAKED spatial softmax multiplies
+# the fp16 rounding of u (exp(u - max) moves by ulp(u) ~ 1-3 %): measured 0.0119 at ONE pixel of the 352 x 1216 DLA-34 map with the
+# 99.9th percentile at 3.8e-4 and the fp32 verification mode at 2.4e-5 on the same map (tools/gpu_z_odd_shape.py) - storage rounding,
+# not wiring.  Bars = 2 x measured.
+Z_PEAK_RTOL = 0.024
+Z_P999_RTOL = 8e-4
+Z_FP32_RTOL = 5e-5
 HM_RTOL = 0.0055       # heat-map logits alone (measured 0.0028): decides which reference detections are safely above the threshold
 VERT_TOL_PX = 0.25    # vertices of matched detections: 16 regression channels x stride 4
 
@@ -148,6 +157,27 @@ def test_decode3d_product_form_vs_published_form(dev):
     np.testing.assert_allclose(b[0][kept], g['raw_x'][kept], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize('kernel', ['wave', 'scalar', 'reference_form'])
+def test_decode3d_large_fixture(dev, kernel):
+    """the TAIL of the device solvers, pinned.  1536 objects the reference solved (SciPy through its own
+    aimFun / jac; tests/golden/decode3d_large.npz, 876 kept, six noise levels) through the product's wave-cooperative kernel
+    (rtm3d_decode3d), its one-lane-per-object twin and the published-form kernel (rtm3d_decode3d_reference_form): keep / reject
+    identical, >= 99.5 % of the kept boxes within north_star's 1e-4, p99 <= 1e-5; the numbers go to the measured-error log."""
+    from tests.util import solver_tail_stats
+    g = load_golden('decode3d_large.npz')
+    x, fun, nit, _ = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'],
+                                                       scalar_kernel=kernel == 'scalar', reference_form=kernel == 'reference_form')
+    s = solver_tail_stats(x, fun, g)
+    record_measurement('decode3d_large_fixture', kernel, s)
+    assert s['n'] >= 1500 and s['keep_mismatch'] == 0 and s['kept'] >= 800, s
+    assert s['within_1e-4'] >= 0.995 and s['p99'] <= 1e-5, s
+    if kernel == 'wave':
+        out = rtm3d_amd.model_utils.optim_decode_bbox3d(g['clses'], g['uv'], g['K'], g['dim_ref'].tolist(), g['ref_loc'].tolist())
+        assert out.get_field('class') == g['out_class'].tolist()
+        d = np.abs(np.asarray(out.get_field('dimension')) - g['out_dimension']).max(1)
+        assert (d <= 1e-4).mean() >= 0.995
+
+
 def test_decode3d_random_vs_scipy(dev):
     """Fresh objects: same answer as the SciPy-driven oracle within 1e-4 (kept objects)."""
     rng = np.random.Generator(np.random.PCG64(2024))
@@ -173,7 +203,11 @@ def _rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max())))
 
 
-E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
+# (the kitti416 pair: the real-KITTI letterbox shape 1 x 3 x 416 x 1280, datasets/dataset_reader.py:55-61 - level4 / level5 maps of
+# 26 x 80 / 13 x 40, where the 8 x 32 halo-tile kernels are not eligible; every test that takes this list runs it: fp16 path,
+# fp32 verification mode, peaks-only regression heads)
+E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz',
+       'e2e_dla34_kitti416.npz', 'e2e_resnet18_kitti416.npz']
 
 
 @pytest.mark.parametrize('fname', E2E)
@@ -266,24 +300,39 @@ def test_sparse_heads_detections_vs_reference_golden(dev, fname):
     assert checked >= 12 * B, checked
 
 
-@pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
-def test_forward_stages_vs_oracle(dev, bb):
-    """Fresh seed, batch 3, non-square small input: backbone features, fused map and logits."""
+@pytest.mark.parametrize('bb,shape', [('DLA-34', (3, 96, 160)), ('RESNET-18', (3, 96, 160)), ('DLA-34', (2, 352, 1216)), ('RESNET-18', (1, 352, 1216)),
+                                      ('DLA-34', (1, 416, 1280))])
+def test_forward_stages_vs_oracle(dev, bb, shape):
+    """Fresh seed: backbone features, fused map and logits against the oracle - batch 3 on a non-square small input; an ODD full-size
+    shape (352 x 1216: maps of 88 x 304 ... 11 x 38, no level takes a halo-tile kernel except by accident of divisibility) and the
+    real-KITTI letterbox shape 416 x 1280."""
+    B, H, W = shape
     sd = weights.synth_state_dict(bb, 11, 'trained', heat_bias=-3.0)
-    x = weights.synth_images(3, 96, 160, seed=77)
+    x = weights.synth_images(B, H, W, seed=77)
     m = make_model(bb, sd)
     logits = m.forward_logits(x.to(dev))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     _, lref, st = rtm3d_ref.model_forward(x, sd, bb, return_stages=True)
-    plan = m._plan_for(3, 96, 160, dev)
+    plan = m._plan_for(B, H, W, dev)
     errs = {}
     for i in range(4):
         errs['feat%d' % i] = _rel_err(plan.download(plan.plan.named['feat%d' % i]), st['feats'][i].numpy())
-    errs['z'] = _rel_err(plan.download(plan.plan.named['z']), st['z'].numpy())
+    zgot, zref = plan.download(plan.plan.named['z']), st['z'].numpy()
+    errs['z'] = _rel_err(zgot, zref)
+    errs['z_p999'] = float(np.percentile(np.abs(zgot - zref), 99.9) / max(1.0, float(np.abs(zref).max())))
     for name, a, b in zip(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset'], logits, lref):
         errs[name] = _rel_err(a.cpu().numpy(), b.numpy())
-    record_measurement('stages_vs_oracle', bb, errs)
+    full = H * W > 100000
+    if full:
+        # the same plan in the fp32 verification mode: the wiring on this shape is the reference's function
+        m.forward_logits_fp32(x.to(dev))
+        errs['z_fp32_mode'] = _rel_err(m._verify[1].fetch('z').cpu().numpy(), zref)
+        m.release_verify()
+    record_measurement('stages_vs_oracle', '%s_%dx%dx%d' % ((bb,) + tuple(shape)), errs)
     for name, e in errs.items():
-        assert e <= (FEAT_RTOL if name.startswith('feat') else Z_RTOL if name == 'z' else LOGIT_RTOL), (name, e)
+        bar = (FEAT_RTOL if name.startswith('feat') else Z_P999_RTOL if name == 'z_p999' else Z_FP32_RTOL if name == 'z_fp32_mode'
+               else (Z_PEAK_RTOL if full else Z_RTOL) if name == 'z' else LOGIT_RTOL)
+        assert e <= bar, (name, e, bar)
 
 
 def _check_device_decode(dev, m, lg, g, K, topk=100):
@@ -517,11 +566,31 @@ def test_config2_dla34_bs32_full_size_properties(dev):
     for a, c in zip(logits, logits2):
         assert torch.equal(a, c)
     assert torch.equal(cls32, det2.cls) and torch.equal(verts32, det2.verts)
+    # images 0 / 13 / 31 of the batch against the ORACLE's fp32 CPU forward of the same images (this replaces
+    # a HIP-vs-HIP comparison at 2e-2): logits at LOGIT_RTOL, detections by the margin rule of the reference-golden tests
+    xc = x.cpu()
+    thr_logit = float(np.log(0.4 / 0.6))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     for b in (0, 13, 31):
+        dref, lref = rtm3d_ref.model_forward(xc[b:b + 1], sd, bb)
+        errs = {}
+        for name, a, c in zip(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset'], logits, lref):
+            errs[name] = _rel_err(a[b:b + 1].cpu().numpy(), c.numpy())
+            assert errs[name] <= LOGIT_RTOL, (b, name, errs[name])
+        record_measurement('config2_bs32_vs_oracle', 'image_%d' % b, errs)
+        tol = HM_RTOL * max(1.0, float(lref[0].abs().max()))
+        kb = int(n[b])
+        got = {(int(c), int(mx // 4), int(my // 4)): v for c, (mx, my), v in
+               zip(cls32[b * 100:b * 100 + kb].cpu().numpy(), mp32[b * 100:b * 100 + kb].cpu().numpy(), verts32[b * 100:b * 100 + kb].cpu().numpy())}
+        if dref[0][0] is not None:
+            rs = dref[1][0].numpy().astype(np.float64)
+            sure = np.abs(np.log(rs / (1.0 - rs)) - thr_logit) > tol
+            for c, mp, v, ok in zip(dref[0][0].numpy(), dref[2][0].numpy(), dref[3][0].numpy(), sure):
+                if ok:
+                    key = (int(c), int(mp[0] // 4), int(mp[1] // 4))
+                    assert key in got, (b, key)
+                    assert np.abs(got[key] - v).max() < VERT_TOL_PX
         d1, b1, l1 = m.detect3d(x[b:b + 1], K[b:b + 1])
-        for a, c in zip(logits, l1):
-            scale = max(1.0, float(a[b:b + 1].abs().max()))
-            assert float((a[b:b + 1] - c).abs().max()) <= 2e-2 * scale
         k = int(n[b])
         sc = score32[b * 100:b * 100 + k].cpu().numpy()
         key32 = {(int(c), tuple(np.floor(mp / 4).astype(int))): v for c, mp, v, s_ in

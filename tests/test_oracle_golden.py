@@ -10,7 +10,8 @@ from rtm3d_amd import weights
 from tests.golden.cases import DECODE2D_CASES, decode2d_inputs, PLANTED_CASES, planted_inputs, DIM_REF
 from tests.util import load_golden, dets_from_golden, to_np, canon_dets
 
-E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz']
+E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz',
+       'e2e_dla34_kitti416.npz', 'e2e_resnet18_kitti416.npz']
 
 
 @pytest.mark.parametrize('fname', E2E)

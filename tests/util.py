@@ -10,6 +10,23 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def solver_tail_stats(x, fun, g):
+    """Solver results (x (N,8), fun) against a reference-run solver fixture (raw_x, raw_fun of decode3d_large.npz): keep / reject
+    mismatches and, over the objects both keep, the per-box L-inf over [Ry, h, w, l, X, Y, Z] (what optim_decode_bbox3d returns,
+    utils/model_utils.py:299-305; the yaw difference taken on the circle): p50 / p99 / max and the share within 1e-4."""
+    kept = g['raw_fun'] < 0.1
+    k2 = np.asarray(fun) < 0.1
+
+    def box(v):
+        return np.concatenate([np.arctan2(v[:, 0], v[:, 1])[:, None], v[:, [3, 4, 2]], v[:, 5:8]], 1)
+    both = kept & k2
+    d = np.abs(box(np.asarray(x)) - box(g['raw_x']))[both]
+    d[:, 0] = np.minimum(d[:, 0], 2 * np.pi - d[:, 0])
+    e = d.max(1)
+    return {'n': int(len(kept)), 'kept': int(kept.sum()), 'keep_mismatch': int((k2 != kept).sum()), 'p50': float(np.percentile(e, 50)),
+            'p99': float(np.percentile(e, 99)), 'max': float(e.max()), 'within_1e-4': float((e <= 1e-4).mean())}
+
+
 def canon_dets(cls, score, *rest):
     """Canonical order (score desc, flat index is unknown here -> cls, x, y as tie-breakers)."""
     cls = np.asarray(cls); score = np.asarray(score)
