@@ -260,6 +260,22 @@ class Model(object):
             self._verify = (key, VerifyPlanF32(ir, x.device))
         return self._verify[1].forward(x, self._head_channels)
 
+    def check_range(self, x, strict=False):
+        """fp16 RANGE REPORT (verification mode; the product path is untouched).  The reference computes in fp32
+        (models/model.py:20-27); this build stores every activation and folded weight as fp16 (|x| <= 65504) without a clamp, so
+        a checkpoint / input whose activations leave that range yields inf or NaN logits in ``forward``.  ``check_range`` runs the
+        recorded plan once in fp32 on ``x`` (``forward_logits_fp32``) and returns ``VerifyPlanF32.range_report()``: one row per
+        written tensor slice and per folded weight array with its largest |value|, the head-room to 65504 and an ``overflow``
+        flag, largest first.  ``strict=True`` raises ``OverflowError`` naming the first offending tensor in plan order."""
+        self.forward_logits_fp32(x)
+        rows = self._verify[1].range_report()
+        if strict:
+            bad = sorted([r for r in rows if r['overflow']], key=lambda r: r['order'])       # the first one in plan order: the cause
+            if bad:
+                raise OverflowError('fp16 range exceeded by %s of op %s: max |x| = %.4g > 65504 (%d tensors in all)'
+                                    % (bad[0]['tensor'], bad[0]['op'], bad[0]['max_abs'], len(bad)))
+        return rows
+
     def release_verify(self):
         """Free the fp32 verification executor's device buffers."""
         self._verify = None

@@ -128,6 +128,46 @@ class VerifyPlanF32(object):
                     raise AssertionError('VerifyPlanF32: unknown op %r' % kind)
         return tuple(outs)
 
+    def range_report(self):
+        """After ``forward``: the largest |value| of every tensor slice an op of the plan writes (fp32 run) and of every folded
+        weight array, against the fp16 range the product path stores them in.  The reference runs in fp32
+        (models/model.py:20-27) and cannot overflow; the product stores activations and weights as fp16 (max 65504) with no
+        clamp: a checkpoint whose activations exceed that yields inf / NaN logits there (which rtm3d_decode2d handles like the
+        reference's own NaN / Inf: tests/test_gpu_parity.py).  Rows: {'what': 'activation' | 'weight', 'op', 'tensor', 'max_abs',
+        'headroom' (65504 / max_abs), 'overflow', 'order' (position in the plan)}, largest first."""
+        FP16_MAX = 65504.0
+        P = self.plan
+        names = {(s.tid, s.coff, s.C): n for n, s in P.named.items()}
+        rows = []
+
+        def act(op_name, s):
+            if s is None:
+                return
+            t = P.tensors[s.tid]
+            pad = t['pad']
+            v = float(self.bufs[s.tid][:, pad:pad + t['H'], pad:pad + t['W'], s.coff:s.coff + s.C].abs().max())
+            rows.append({'what': 'activation', 'order': len(rows), 'op': op_name, 'tensor': names.get((s.tid, s.coff, s.C), 'tensor%d[%d:%d]' % (s.tid, s.coff, s.coff + s.C)),
+                         'max_abs': v, 'headroom': FP16_MAX / v if v > 0 else float('inf'), 'overflow': not (v <= FP16_MAX)})
+
+        for op in P.ops:
+            kind = op['op']
+            if kind == 'conv':
+                for o in op['out']:
+                    act(op['name'], o)
+                w = float(np.abs(op['w']).max())
+                rows.append({'what': 'weight', 'order': len(rows), 'op': op['name'], 'tensor': 'folded weights', 'max_abs': w,
+                             'headroom': FP16_MAX / w if w > 0 else float('inf'), 'overflow': not (w <= FP16_MAX)})
+            elif kind == 'headout':
+                w = max(float(np.abs(x).max()) for x in op['w'])
+                rows.append({'what': 'weight', 'order': len(rows), 'op': op['name'], 'tensor': 'folded weights', 'max_abs': w,
+                             'headroom': FP16_MAX / w if w > 0 else float('inf'), 'overflow': not (w <= FP16_MAX)})
+            elif kind == 'maxpool':
+                act(op['name'], op['out'])
+            elif kind == 'softmax':
+                act(op['name'], op['z_out'])
+        rows.sort(key=lambda r: -r['max_abs'] if r['max_abs'] == r['max_abs'] else -float('inf'))
+        return rows
+
     def fetch(self, name):
         """Stage output by its plan name (e.g. 'z', 'feat3') as fp32 NCHW, for parity tests."""
         s = self.plan.named[name]

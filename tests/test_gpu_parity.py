@@ -1262,3 +1262,44 @@ def test_fp32_verify_end_to_end_boxes_vs_reference(dev):
     # Measured: median 6e-6, maximum 8.2e-4; the reference under 3e-5 px of input noise: 2.1e-3 (bar = 2 x that).
     assert f['box_median'] <= 1e-4 and f['box_linf'] <= 4.2e-3, f
     assert f['boxes_within_1e-4'] >= int(0.75 * f['kept_ref']), f
+
+
+def test_fp16_range_report_names_the_overflowing_tensor(dev):
+    """the product path stores activations as fp16 with no clamp.  Model.check_range (fp32 verification
+    executor) reports, per written tensor, max |x| against 65504.  A healthy state dict has head-room everywhere; with ONE
+    backbone BatchNorm scaled so that level3's first block leaves the fp16 range the report names that tensor (and the ones
+    downstream), strict=True raises naming the first one in plan order, and the PRODUCT path's logits for that input are silently
+    wrong (see below); non-finite logits reach decode2d as the NaN / Inf cells the decode tests cover."""
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 3, 'trained', heat_bias=-3.0)
+    x = weights.synth_images(1, 128, 256, seed=5).to(dev)
+    m = make_model(bb, sd)
+    rows = m.check_range(x, strict=True)
+    acts = [r for r in rows if r['what'] == 'activation']
+    assert len(acts) >= 40 and not any(r['overflow'] for r in rows)
+    assert min(r['headroom'] for r in rows) > 50, rows[0]                 # the synthetic checkpoints sit far inside the range
+    record_measurement('fp16_range', 'healthy', {'largest': rows[0]['max_abs'], 'tensor': rows[0]['tensor'], 'op': rows[0]['op']})
+    m.release_verify()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2['backbone.level3.tree1.tree1.norm1.weight'] *= 3.0e5
+    m2 = make_model(bb, sd2)
+    rows2 = m2.check_range(x)
+    bad = [r for r in rows2 if r['overflow']]
+    assert bad and any(r['op'] == 'backbone.level3.tree1.tree1.conv1' for r in bad), [(r['op'], r['max_abs']) for r in rows2[:5]]
+    with pytest.raises(OverflowError, match='backbone.level3'):
+        m2.check_range(x, strict=True)
+    # what the PRODUCT path does with that checkpoint: nothing announces the overflow.  The stores round the out-of-range values
+    # to +-inf; an inf times weights of both signs sums to NaN; and the kernels' ReLU is v_pk_max_f16, an IEEE maxNum, which
+    # returns 0 for a NaN operand (torch.relu in the reference would propagate it) - so the logits may come out as non-finite
+    # values OR as finite garbage.  Either way they are far from the fp32 run's, which is why check_range exists.
+    ref32 = [l.clone() for l in m2.forward_logits_fp32(x)]
+    logits = m2.forward_logits(x)
+    torch.cuda.synchronize()
+    finite = all(bool(torch.isfinite(l).all()) for l in logits)
+    gross = max(float((a - b).abs().max() / b.abs().max().clamp_min(1.0)) for a, b in zip(logits, ref32)) if finite else float('inf')
+    record_measurement('fp16_range', 'overflowing', {'first_bad_op': sorted(bad, key=lambda r: r['order'])[0]['op'], 'tensors_over': len(bad),
+                                                     'product_logits_finite': finite, 'product_vs_fp32_rel_err': gross if finite else -1.0})
+    assert (not finite) or gross > 0.5, gross
+    d = m2.inference([l.clone() for l in logits])                        # ... which the decode handles (no crash, no NaN-scored detection)
+    if d[0][0] is not None:
+        assert bool(torch.isfinite(d[1][0]).all())
