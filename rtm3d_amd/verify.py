@@ -55,8 +55,27 @@ class VerifyPlanF32(object):
         v.Hp, v.Wp, v.C, v.P, v.coff = t['H'] + 2 * t['pad'], t['W'] + 2 * t['pad'], t['C'], t['pad'], s.coff
         return v
 
-    def forward(self, x, head_channels):
-        """x: (B, 3, H, W) fp32 CUDA tensor -> tuple of fp32 NCHW logit maps (models/model.py:21-23)."""
+    def _fp16_parts(self, op, fp16):
+        """[(lo, hi)] output-channel ranges (relative to each output slice) of `op` that the emulation stores as fp16.
+        `fp16(name, part, nparts)`: the plan's four-branch head ops are asked per branch (the fused first head conv's 256-channel
+        chunks, the groups of the second, the heads of the logit convs), every other op once."""
+        if fp16 is None:
+            return []
+        if op['op'] == 'headout':
+            return [(h, h + 1) for h in range(len(op['w'])) if fp16(op['name'], h, len(op['w']))]       # (head indices)
+        if op['op'] == 'conv' and op['groups'] == 1 and op['cout'] % 256 == 0 and op['cout'] > 256 and op['name'].startswith('heads'):
+            n = op['cout'] // 256
+            return [(g * 256, g * 256 + 256) for g in range(n) if fp16(op['name'], g, n)]
+        if op['op'] == 'conv' and op['groups'] > 1 and op['name'].startswith('heads'):
+            return [(g, g + 1) for g in range(op['groups']) if fp16(op['name'], g, op['groups'])]              # (group indices)
+        return [(0, None)] if fp16(op['name'], 0, 1) else []
+
+    def forward(self, x, head_channels, fp16=None):
+        """x: (B, 3, H, W) fp32 CUDA tensor -> tuple of fp32 NCHW logit maps (models/model.py:21-23).
+        fp16 (error apportioning, tools/gpu_error_apportioning.py): callable (op name, part, parts) -> bool; the ops / head
+        branches it selects are EMULATED in the product's storage precision - weights rounded to fp16, the written activations
+        rounded to fp16 after the op (accumulation stays fp64 -> fp32): a mixed-precision replay that tells which stage's
+        fp16 storage carries the end-to-end error.  None: everything fp32 (the verification mode)."""
         P, lib = self.plan, self.lib
         B = P.B
         if tuple(x.shape) != (B, 3, P.H, P.W) or not x.is_cuda or x.dtype != torch.float32:
@@ -73,7 +92,10 @@ class VerifyPlanF32(object):
                     pad = t['pad']
                     # layout change only (NCHW -> the NHWC4 operand of the stem, 4th channel stays zero)
                     self.bufs[o.tid][:, pad:pad + t['H'], pad:pad + t['W'], 0:3] = x.permute(0, 2, 3, 1)
+                    if fp16 is not None and fp16(op['name'], 0, 1):
+                        self.bufs[o.tid].copy_(self.bufs[o.tid].half().float())
                 elif kind == 'conv':
+                    parts = self._fp16_parts(op, fp16)
                     for g in range(op['groups']):
                         d = _lib.VConvDesc()
                         d.inp = self._vt(op['inp'][g])
@@ -85,6 +107,15 @@ class VerifyPlanF32(object):
                         if op['res'][g] is not None:
                             d.res = self._vt(op['res'][g])
                         w, b = self._w[k][g]
+                        if parts:
+                            # fp16 weights for the emulated part: whole array (lo, None), 256-column chunks of a fused conv, or this group
+                            if op['groups'] > 1 and op['name'].startswith('heads'):
+                                if (g, g + 1) in parts:
+                                    w = w.half().float()
+                            else:
+                                w = w.clone()
+                                for lo, hi in parts:
+                                    w[..., lo:hi] = w[..., lo:hi].half().float()
                         d.d_w, d.d_bias = w.data_ptr(), b.data_ptr()
                         d.B, d.Hm, d.Wm, d.in_stride, d.out_scale = B, op['Hm'], op['Wm'], op['in_stride'], op['out_scale']
                         d.out_oy, d.out_ox = op['out_off'][g]
@@ -92,7 +123,22 @@ class VerifyPlanF32(object):
                         for t, (dy, dx) in enumerate(op['taps'][g]):
                             d.tap_dy[t], d.tap_dx[t] = dy, dx
                         _lib.check(lib.rtm3d_verify_conv_f32(stream, ctypes.byref(d)), 'verify_conv_f32(%s)' % op['name'])
+                        if parts:
+                            torch.cuda.current_stream(dev).synchronize()          # `w` may be a temporary
+                    if parts and not op['out_nchw']:
+                        if op['groups'] > 1 and op['name'].startswith('heads'):
+                            for g, _ in parts:
+                                o = op['out'][g]
+                                v = self.bufs[o.tid][..., o.coff:o.coff + o.C]
+                                v.copy_(v.half().float())
+                        else:
+                            o = op['out'][0]
+                            for lo, hi in parts:
+                                a, bnd = o.coff + lo, o.coff + (o.C if hi is None else hi)
+                                v = self.bufs[o.tid][..., a:bnd]
+                                v.copy_(v.half().float())
                 elif kind == 'headout':
+                    hparts = [h for h, _ in self._fp16_parts(op, fp16)]
                     taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
                     for h, (w, b) in enumerate(self._w[k]):
                         d = _lib.VConvDesc()
@@ -100,12 +146,16 @@ class VerifyPlanF32(object):
                         d.inp.coff = op['inp'].coff + h * 256
                         d.out.d = outs[h].data_ptr()
                         d.out_nchw_f32, d.out_H, d.out_W = 1, P.H // 4, P.W // 4
+                        if h in hparts:
+                            w = w.half().float()
                         d.d_w, d.d_bias = w.data_ptr(), b.data_ptr()
                         d.B, d.Hm, d.Wm, d.in_stride, d.out_scale = B, P.H // 4, P.W // 4, 1, 1
                         d.cin, d.cout, d.ntaps, d.relu = 256, int(w.shape[2]), 9, 0
                         for t, (dy, dx) in enumerate(taps):
                             d.tap_dy[t], d.tap_dx[t] = dy, dx
                         _lib.check(lib.rtm3d_verify_conv_f32(stream, ctypes.byref(d)), 'verify_conv_f32(%s)' % op['name'])
+                        if hparts:
+                            torch.cuda.current_stream(dev).synchronize()
                 elif kind == 'maxpool':
                     i, o = self._vt(op['inp']), self._vt(op['out'])
                     Ho, Wo = P.dims(op['out'])
@@ -124,6 +174,10 @@ class VerifyPlanF32(object):
                         self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
                     _lib.check(lib.rtm3d_verify_softmax_fuse_f32(stream, ctypes.byref(zi), ctypes.byref(zo), n_u, us, B, H, W, C,
                                                                  self._ws.data_ptr()), 'verify_softmax_fuse_f32')
+                    if self._fp16_parts(op, fp16):
+                        o = op['z_out']
+                        v = self.bufs[o.tid][..., o.coff:o.coff + o.C]
+                        v.copy_(v.half().float())
                 else:
                     raise AssertionError('VerifyPlanF32: unknown op %r' % kind)
         return tuple(outs)
