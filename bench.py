@@ -469,15 +469,19 @@ def launch_ranks(n, argv):
     import subprocess
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL needs it on this driver)
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    # threads per rank from what this process may really use (scheduler affinity / cgroup quota, the figure cpu_baseline reports),
+    # not from os.cpu_count(): 8 ranks x 32 OpenMP threads inside a 16-CPU quota only time-slice against each other while every
+    # rank folds BatchNorms and draws its synthetic images
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cpu_info()['usable'] // n)))
     env['RTM3D_BENCH_LAUNCHED'] = '1'
+    env['RTM3D_BENCH_SPAWN_T'] = repr(time.time())          # wall clock at spawn: ranks report spawn -> first timed step
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
     print('bench.py: starting %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr)
     return subprocess.run(cmd, env=env).returncode
 
 
-def multi_diagnostics(world, B, steps, dt, rec, local, dev, gather_us):
+def multi_diagnostics(world, B, steps, dt, rec, local, dev, gather_us, startup_s=None):
     """Diagnostics of an N-rank run, outside the timed region: max-over-ranks wall time, every rank's own ms/step, and how
     many ranks' record blocks arrived intact in this rank's gathered batch (checksum of each rank's local block, gathered
     separately, against the block sums of the gathered records)."""
@@ -500,7 +504,22 @@ def multi_diagnostics(world, B, steps, dt, rec, local, dev, gather_us):
     multi['gathered_shape'] = list(rec.shape)
     multi['allgather_us_last_step'] = round(gather_us, 1) if gather_us is not None else None
     multi['allgather_bytes_per_rank'] = int(local.numel() * 4)
+    if startup_s is not None:
+        # wall time from the launcher's spawn to this rank's first timed step (process start, imports, weight synthesis + BN folding,
+        # plan recording, warm-up): the slowest rank's, i.e. what an N-rank run costs before it measures anything
+        su = torch.tensor([startup_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(su, op=dist.ReduceOp.MAX)
+        multi['startup_s_spawn_to_first_timed_step'] = round(float(su.item()), 2)
+        multi['omp_threads_per_rank'] = int(os.environ.get('OMP_NUM_THREADS', '0') or 0)
     return float(t.item()), multi
+
+
+def _startup_s(t0_perf):
+    """Seconds from the launcher's spawn (RTM3D_BENCH_SPAWN_T, wall clock) to the start of the timed region (perf_counter t0)."""
+    spawn = os.environ.get('RTM3D_BENCH_SPAWN_T')
+    if not spawn:
+        return None
+    return (time.time() - (time.perf_counter() - t0_perf)) - float(spawn)
 
 
 def dry_launch(args, world, rank):
@@ -530,7 +549,7 @@ def dry_launch(args, world, rank):
         rec = rdist.all_gather_records(local, always=True, out=out)
     fence()
     dt = time.perf_counter() - t0
-    dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, None)
+    dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, None, _startup_s(t0))
     multi['block_ranks'] = [int(v) for v in rec.reshape(world, B, topk, rdist.RECORD)[:, 0, 0, 0].tolist()]
     if rank == 0:
         print(json.dumps({'metric': 'images_per_sec', 'value': None, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
@@ -644,7 +663,8 @@ def main():
     rec, det = step()
     torch.cuda.synchronize(dev)
     plan = model._plan_for(B, H, W, dev, 'peaks' if args.sparse_heads else 'dense')
-    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in ((3,) if args.sparse_heads else (3, 16, 2, 2))]
+    head_ch = list(model._head_channels)                     # (num_classes, 16, 2, 2) for the rtm3d head table
+    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in (head_ch[:1] if args.sparse_heads else head_ch)]
     stream = torch.cuda.current_stream(dev).cuda_stream
     optrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
     plan.forward_timed(stream, x.data_ptr(), optrs)
@@ -685,7 +705,8 @@ def main():
     if use_dist:
         torch.cuda.synchronize(dev)
         local = pipe.rec_local[last_step % pipe.depth] if pipe is not None else rec[rank * B:(rank + 1) * B]
-        dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, pipe.gather_us(last_step) if pipe is not None else None)
+        dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, pipe.gather_us(last_step) if pipe is not None else None,
+                                      _startup_s(t0))
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

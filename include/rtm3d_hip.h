@@ -167,8 +167,18 @@ int rtm3d_forward(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const 
 /* enable != 0: rtm3d_forward replays the plan as ONE hipGraph launch instead of ~60 kernel launches (small batches are
  * launch-gap bound; the reference's detect.py runs bs = 1).  The graph is captured on first use per distinct
  * (d_in, d_out_logits[0..3]) pointer tuple - kernel arguments are baked into it - and up to 8 tuples are cached (LRU).
- * Results are bit-identical to the eager replay.  The live probe (rtm3d_probe_set) forces the eager path.            */
+ * Results are bit-identical to the eager replay.  The live probe (rtm3d_probe_set) forces the eager path.
+ * RULE - ALL-KERNEL GRAPHS ONLY: nothing that runs during a replay may be a hipMemset*Async / hipMemcpy*Async (they become
+ * memset / memcpy graph NODES).  With three or more graph execs of different node counts alive in one context, re-launching an
+ * older exec ran the kernel node behind its memset node with stale arguments (round 3: a conversion pass silently had no effect,
+ * a convolution took a memory-access fault; all-kernel graphs alternate correctly), which is why the ticket counters are zeroed
+ * by a kernel.  The rule is enforced: after every capture the node types are enumerated (hipGraphGetNodes /
+ * hipGraphNodeGetType); a graph with any non-kernel node is destroyed, the context leaves graph mode for good, the call is
+ * served by the eager replay and rtm3d_last_error() says why (rtm3d_ctx_graph_stats reports enabled = 0).               */
 int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable);
+/* TEST HOOK for the rule above: enable != 0 puts one hipMemsetAsync in front of every replay, so that a capture holds a memset
+ * node and must be refused (tests/test_gpu_kernels.py::test_graph_with_memset_node_is_refused).  Never set by the product.  */
+int rtm3d_ctx_debug_memset_in_replay(rtm3d_ctx* ctx, int enable);
 /* Graph bookkeeping of a context: captures made, replays served from the cache, whether graph mode is still on (a caller that
  * hands over fresh buffers on every call makes every call a capture; after 32 captures without as many hits the context gives
  * up on graphs - Model.forward_logits(out=...) keeps the addresses stable).  Any pointer may be NULL.                      */
@@ -208,11 +218,14 @@ int rtm3d_decode2d(void* stream, const float* d_main_kf, const float* d_offset_f
  * rtm3d_gather_peak_patches: after rtm3d_decode2d in its peaks-only mode, copy for every live slot the samples of the fused
  * map z (padded NHWC fp16, 256 channels, border z_pad) that the three head convolutions of a peak depend on into a
  * 15 x 15 x 256 patch (layout: csrc/sparse_heads.hip) and the peak's (y, x) into d_yx; empty slots get (-1, -1).
+ * The caller states the CAPACITY of what is written: d_patch holds patch_slots windows of patch_S x patch_S x 256 halves, d_yx
+ * yx_bytes bytes; the call is refused unless patch_S == 15, patch_slots >= B * topk and yx_bytes >= 8 * B * topk.
  * rtm3d_decode2d_finish: sub-pixel key point, 8 vertices and the 2D box of every live slot from the regression logits
  * evaluated at its peak ([B*topk][16] and [B*topk][2] fp32) - the second half of rtm3d_decode2d, same fp32 operation order;
  * d_mproj holds the integer key points on entry and the sub-pixel ones (x down_sample) on return.                      */
 int rtm3d_gather_peak_patches(void* stream, const void* d_z, int z_H, int z_W, int z_C, int z_pad, int B, int topk,
-                              const int32_t* d_n, const float* d_peak_xy, void* d_patch, int32_t* d_yx);
+                              const int32_t* d_n, const float* d_peak_xy, void* d_patch, int32_t* d_yx,
+                              int patch_slots, int patch_S, size_t yx_bytes);
 int rtm3d_decode2d_finish(void* stream, int B, int topk, const int32_t* d_n, const float* d_reg_offset_fr_main,
                           const float* d_reg_main_offset, float down_sample, float* d_mproj, float* d_verts, float* d_bbox);
 

@@ -71,12 +71,14 @@ SIGNATURES = {
     'rtm3d_op_conv64_root': (c_int, [c_void_p] + [c_int] * 14),
     'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_patch_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
-    'rtm3d_gather_peak_patches': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rtm3d_gather_peak_patches': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_size_t]),
     'rtm3d_decode2d_finish': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_forward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
     'rtm3d_ctx_set_graph': (c_int, [c_void_p, c_int]),
+    'rtm3d_ctx_debug_memset_in_replay': (c_int, [c_void_p, c_int]),
     'rtm3d_ctx_graph_stats': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_char_p)]),

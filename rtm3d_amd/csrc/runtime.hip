@@ -77,7 +77,8 @@ struct rtm3d_ctx {
     hipEvent_t done_ev = nullptr;
     struct GraphEntry { const void* key[5]; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
     std::vector<GraphEntry> graphs;
-    unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0;
+    unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0, graph_refused = 0;
+    int test_memset_in_replay = 0;     // rtm3d_ctx_debug_memset_in_replay: a hipMemsetAsync in front of every replay (tests the guard above)
 };
 static const int PROBE_RING = 64;
 static const int TICKET_SLOTS = 56;
@@ -720,6 +721,7 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
     // way) they would be left non-zero and later launches would silently skip tiles.  Zeroing them in stream order at
     // the head of every replay costs one tiny launch (zero_counters).
     RT_HIP(zero_counters(ctx, s));
+    if (ctx->test_memset_in_replay && ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, sizeof(unsigned int), s));   // (test hook only)
     const int n = (int)ctx->ops.size();
     for (int i = 0; i < n; ++i) {
         const bool probe = probes && (i == ctx->probe_op);
@@ -732,6 +734,21 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
 }
 
 static const size_t GRAPH_CACHE = 8;
+
+// number of nodes of `graph` that are not kernel nodes (-1: the runtime could not enumerate them, treated as a refusal)
+static int graph_non_kernel_nodes(hipGraph_t graph) {
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) return -1;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) return -1;
+    int bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) return -1;
+        if (ty != hipGraphNodeTypeKernel) ++bad;
+    }
+    return bad;
+}
 
 static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float* const d_out_logits[4]);
 
@@ -778,6 +795,20 @@ static int forward_on_stream(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, f
     const hipError_t ec = hipStreamEndCapture(ctx->capture_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
     if (ec != hipSuccess) { rt_set_error("forward: graph capture failed: %s", hipGetErrorString(ec)); return 1; }
+    // ALL-KERNEL GRAPHS ONLY (include/rtm3d_hip.h, rtm3d_ctx_set_graph): with several graph execs of different node counts alive,
+    // re-launching an older exec ran the kernel node behind a memset node with stale arguments (round 3).  Nothing in this file
+    // captures a hipMemset*Async / hipMemcpy*Async today; if a future op launcher does, the capture is refused here instead of
+    // bringing the fault back: the graph is dropped, the context leaves graph mode and this replay runs eagerly.
+    {
+        int bad = graph_non_kernel_nodes(graph);
+        if (bad != 0) {
+            (void)hipGraphDestroy(graph);
+            ctx->graph_mode = 0;
+            ctx->graph_refused++;
+            rt_set_error("forward: the captured plan holds %d non-kernel graph node(s) (memset / memcpy nodes are not allowed in a replay graph); graph mode is off for this context", bad);
+            return replay_eager(ctx, s, d_in, d_out_logits, true);
+        }
+    }
     rtm3d_ctx::GraphEntry ge;
     memcpy(ge.key, key, sizeof(key));
     ge.graph = graph;
@@ -817,6 +848,13 @@ extern "C" int rtm3d_ctx_graph_stats(rtm3d_ctx* ctx, int* captures, int* hits, i
     if (captures) *captures = (int)ctx->graph_captures;
     if (hits) *hits = (int)ctx->graph_hits;
     if (enabled) *enabled = ctx->graph_mode;
+    return 0;
+}
+
+extern "C" int rtm3d_ctx_debug_memset_in_replay(rtm3d_ctx* ctx, int enable) {
+    if (!ctx) RT_FAIL("ctx_debug_memset_in_replay: null context");
+    if (ensure_tile_ctr(ctx)) return 1;
+    ctx->test_memset_in_replay = enable ? 1 : 0;
     return 0;
 }
 

@@ -60,8 +60,15 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const PatchGatherArgs
 }
 
 extern "C" int rtm3d_gather_peak_patches(void* stream, const void* d_z, int z_H, int z_W, int z_C, int z_pad, int B, int topk,
-                                         const int32_t* d_n, const float* d_peak_xy, void* d_patch, int32_t* d_yx) {
+                                         const int32_t* d_n, const float* d_peak_xy, void* d_patch, int32_t* d_yx,
+                                         int patch_slots, int patch_S, size_t yx_bytes) {
     if (!d_z || !d_n || !d_peak_xy || !d_patch || !d_yx) { rt_set_error("gather_peak_patches: null pointer"); return 1; }
+    // capacity of what the kernel writes: B * topk patches of SP_PATCH x SP_PATCH x 256 halves and 2 int32 per slot
+    if (patch_S != SP_PATCH || B <= 0 || topk <= 0 || (long long)patch_slots < (long long)B * topk || yx_bytes < (size_t)8 * B * topk) {
+        rt_set_error("gather_peak_patches: the patch tensor (%d slots of %d x %d) / (y, x) blob (%zu bytes) cannot hold %d x %d slots of %d x %d",
+                     patch_slots, patch_S, patch_S, yx_bytes, B, topk, SP_PATCH, SP_PATCH);
+        return 1;
+    }
     if (B <= 0 || topk <= 0 || z_H <= 0 || z_W <= 0 || z_C != 256 || z_pad < 0) { rt_set_error("gather_peak_patches: bad shape (the fused map has 256 channels)"); return 1; }
     PatchGatherArgs a;
     a.z = (const f16*)d_z; a.z_Hp = z_H + 2 * z_pad; a.z_Wp = z_W + 2 * z_pad; a.z_C = z_C; a.z_P = z_pad; a.H = z_H; a.W = z_W;

@@ -239,6 +239,8 @@ class Model(object):
                         raise ValueError('forward_logits: out tensors must be contiguous fp32 %s on %s' % (shapes, dev))
             ptrs = [o.data_ptr() for o in outs] + [0] * (4 - len(outs))
             plan.forward(torch.cuda.current_stream(dev).cuda_stream, xptr, ptrs)
+            # which heat map the fused map z inside this plan belongs to (decode2d_sparse refuses any other)
+            plan.z_stamp = (getattr(plan, 'z_stamp', (0, 0))[0] + 1, outs[0].data_ptr())
         return tuple(outs)
 
     def forward_logits_fp32(self, x):
@@ -298,16 +300,27 @@ class Model(object):
         B, _, Hm, Wm = hm.shape
         dev = hm.device
         plan = self._plan_for(B, 4 * Hm, 4 * Wm, dev, 'peaks')
+        # the patches are gathered from the fused map z INSIDE the plan: it must still be the z of the forward that produced
+        # `hm`.  A plan that was evicted and rebuilt (MAX_PLANS) holds no z at all, and another forward of this shape in between
+        # has overwritten it - both would give plausible but wrong vertices, silently
+        stamp = getattr(plan, 'z_stamp', None)
+        if stamp is None or stamp[1] != hm.data_ptr():
+            raise RuntimeError('decode2d_sparse: the plan of this shape does not hold the fused map of these heat-map logits (%s); call '
+                               "forward_logits(x, heads='peaks') and decode2d_sparse on its result back to back"
+                               % ('the plan was rebuilt since' if stamp is None else 'another forward of this shape ran in between'))
         det = self.decode2d((hm,), out=out, peaks_only=True)
         lib = _lib.load()
         topk = det.topk
         zbase, zB, zH, zW, zC, zP = plan.tensor_info(plan.plan.named['z'])
-        pbase = plan.peak.tensor_info(plan.peak.plan.named['zp'])[0]
+        pbase, pslots, pS, _, pC, pP = plan.peak.tensor_info(plan.peak.plan.named['zp'])
+        if pC != 256 or pP != 0:
+            raise RuntimeError('decode2d_sparse: the patch plan input must be a borderless 256-channel tensor')
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.rtm3d_gather_peak_patches(ctypes.c_void_p(stream), ctypes.c_void_p(zbase), zH, zW, zC, zP, B, topk,
                                                      det.n.data_ptr(), det.mproj.data_ptr(), ctypes.c_void_p(pbase),
-                                                     ctypes.c_void_p(plan.peak.blob_address(plan.peak.yx_blob))), 'gather_peak_patches')
+                                                     ctypes.c_void_p(plan.peak.blob_address(plan.peak.yx_blob)),
+                                                     pslots, pS, plan.peak.blob_bytes(plan.peak.yx_blob)), 'gather_peak_patches')
             plan.peak.forward(stream, 0, [t.data_ptr() for t in plan.peak_out] + [0, 0])
             _lib.check(lib.rtm3d_decode2d_finish(ctypes.c_void_p(stream), B, topk, det.n.data_ptr(), plan.peak_out[0].data_ptr(),
                                                  plan.peak_out[1].data_ptr(), float(self.config.MODEL.DOWN_SAMPLE),

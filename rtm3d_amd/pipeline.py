@@ -152,11 +152,14 @@ class Detect3DPipeline(object):
         self.count += 1
         return i
 
-    def results(self, i):
-        """(world*B, topk, 32) records of step i (waits for it on the current stream)."""
+    def results(self, i, copy=False):
+        """(world*B, topk, 32) records of step i (waits for it on the current stream).
+        LIFETIME: the tensor is the slot's preallocated buffer, not a fresh one: it is overwritten by step i + depth (with
+        world > 1: by that step's all-gather on a side stream).  Read it - on the stream that called results(), which is the one
+        ordered behind the step - before `depth` further submits, or pass copy=True for a private clone made on that stream."""
         s = i % self.depth
         torch.cuda.current_stream(self.dev).wait_event(self.ev_b[s])
-        return self.rec[s]
+        return self.rec[s].clone() if copy else self.rec[s]
 
     def gather_us(self, i):
         """Device time of step i's collective in microseconds (needs time_gather = True before the step; waits for it)."""

@@ -1006,6 +1006,11 @@ class RealizedPlan(object):
         _lib.check(self.lib.rtm3d_blob_address(self.ctx, bid, ctypes.byref(p), ctypes.byref(n)), 'blob_address')
         return p.value
 
+    def blob_bytes(self, bid):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _lib.check(self.lib.rtm3d_blob_address(self.ctx, bid, ctypes.byref(p), ctypes.byref(n)), 'blob_address')
+        return int(n.value)
+
     def _op_softmax(self, op):
         us = (ctypes.c_int * len(op['us']))(*[self.tids[u.tid] for u in op['us']])
         _lib.check(self.lib.rtm3d_op_softmax_fuse(self.ctx, self.tids[op['z_in'].tid], self.tids[op['z_out'].tid], len(op['us']), us),

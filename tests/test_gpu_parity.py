@@ -995,6 +995,40 @@ def test_graph_relaunch_orders_of_mixed_structure(dev, bb, B, H, W):
     assert run(lambda s: None, bb, B, H, W, rounds=30) == 0
 
 
+def test_graph_with_memset_node_is_refused(dev):
+    """ADVICE r03 / the rule in include/rtm3d_hip.h (rtm3d_ctx_set_graph): replay graphs hold kernel nodes only.  With the test
+    hook that puts a hipMemsetAsync in front of every replay, the capture contains a memset node: the runtime must drop the
+    graph, leave graph mode (graph_stats: enabled = False) and serve the call - and every later one - by the eager replay, with
+    results equal to a context that never used graphs; without the hook the same plan captures normally (captures >= 1)."""
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0)
+    mg, me = make_model(bb, sd), make_model(bb, sd)
+    mg.use_graph, me.use_graph = True, False
+    x = weights.synth_images(1, 64, 128, seed=3).to(dev)
+    ref = [l.clone() for l in me.forward_logits(x)]
+    plan = mg._plan_for(1, 64, 128, dev)
+    lib = _lib.load()
+    _lib.check(lib.rtm3d_ctx_debug_memset_in_replay(plan.ctx, 1), 'debug_memset_in_replay')
+    for _ in range(3):
+        got = mg.forward_logits(x)
+        torch.cuda.synchronize()
+        for u, v in zip(got, ref):
+            assert torch.equal(u, v)
+    cap, hits, enabled = plan.graph_stats()
+    assert enabled is False and hits == 0, (cap, hits, enabled)
+    assert b'non-kernel graph node' in lib.rtm3d_last_error()
+    # the same plan without the hook: graphs work (a fresh context: this one has left graph mode for good)
+    m2 = make_model(bb, sd)
+    m2.use_graph = True
+    outs = m2.forward_logits(x, out='reuse')
+    outs = m2.forward_logits(x, out='reuse')
+    torch.cuda.synchronize()
+    cap2, hits2, enabled2 = m2._plan_for(1, 64, 128, dev).graph_stats()
+    assert enabled2 is True and cap2 >= 1 and hits2 >= 1, (cap2, hits2, enabled2)
+    for u, v in zip(outs, ref):
+        assert torch.equal(u, v)
+
+
 def test_forward_logits_out_keeps_one_graph(dev):
     """a bs=1 loop that HOLDS its outputs gets fresh logit tensors on every call, i.e. a new graph key and
     a capture per call until the context gives up on graphs after 32; with out='reuse' (or explicit out= tensors) the same
