@@ -289,14 +289,17 @@ class Model(object):
             return pred_logits
         return self.inference(pred_logits), pred_logits
 
-    def decode2d_sparse(self, heat_logits, out=None):
+    def decode2d_sparse(self, heat_logits, out=None, from_forward=None):
         """2D decode with the regression branches evaluated at the detected peaks only (what Model.inference reads of
         them: models/model.py:47-50,124-128): peaks from the dense heat map (NMS + top-k, identical to decode2d's), the z
         samples each peak depends on gathered into patches, the three head convs of branches offset_fr_main / main_offset as a
         patch plan on the MFMA conv kernels, then the sub-pixel / vertex arithmetic of decode2d.  heat_logits: the 1-tuple of
         ``forward_logits(x, heads='peaks')`` (its plan still holds the fused map z of that forward: call this next, on the
-        same stream).  Same Detections as decode2d on the dense logits, vertices to fp16 round-off of the network."""
+        same stream).  Same Detections as decode2d on the dense logits, vertices to fp16 round-off of the network.
+        from_forward: when heat_logits is an edited COPY of what forward_logits returned (tests plant peaks), the original
+        tuple - the freshness check below is made on it."""
         hm = heat_logits[0] if isinstance(heat_logits, (tuple, list)) else heat_logits
+        hm_src = hm if from_forward is None else (from_forward[0] if isinstance(from_forward, (tuple, list)) else from_forward)
         B, _, Hm, Wm = hm.shape
         dev = hm.device
         plan = self._plan_for(B, 4 * Hm, 4 * Wm, dev, 'peaks')
@@ -304,7 +307,7 @@ class Model(object):
         # `hm`.  A plan that was evicted and rebuilt (MAX_PLANS) holds no z at all, and another forward of this shape in between
         # has overwritten it - both would give plausible but wrong vertices, silently
         stamp = getattr(plan, 'z_stamp', None)
-        if stamp is None or stamp[1] != hm.data_ptr():
+        if stamp is None or stamp[1] != hm_src.data_ptr() or tuple(hm_src.shape) != tuple(hm.shape):
             raise RuntimeError('decode2d_sparse: the plan of this shape does not hold the fused map of these heat-map logits (%s); call '
                                "forward_logits(x, heads='peaks') and decode2d_sparse on its result back to back"
                                % ('the plan was rebuilt since' if stamp is None else 'another forward of this shape ran in between'))

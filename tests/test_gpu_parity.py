@@ -837,8 +837,10 @@ def test_sparse_heads_equal_dense_heads_at_the_peaks(dev, bb, B, H, W, hb):
         for k_, (r, c) in enumerate(cells):
             hm[0, k_ % 3, max(r - 1, 0):r + 2, max(c - 1, 0):c + 2] = -9.0
             hm[0, k_ % 3, r, c] = 6.0 + 0.01 * k_
+        det_s = m.decode2d_sparse((hm,), from_forward=lg_s)             # the plan still holds z of the forward above
+        with pytest.raises(RuntimeError, match='does not hold the fused map'):
+            m.decode2d_sparse((hm,))                                     # an unrelated tensor: refused
         lg_s = (hm,)
-        det_s = m.decode2d_sparse(lg_s)             # the plan still holds z of the forward above
         box_s = decode3d_slots(det_s, K, m.config.DETECTOR.dim_ref, [0, -0.5, 20])
         torch.cuda.synchronize()
         lg_d = (hm,) + tuple(lg_d[1:])
