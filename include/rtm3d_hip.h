@@ -95,7 +95,8 @@ typedef struct rtm3d_conv_desc {
     int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 2 = MFMA 256x256 tile
                                               (cout % 256 == 0), 3 = register-direct MFMA (cin 4/16/32), 5 = 64->64 3x3 halo kernel,
                                               filter bank in registers (W % 32 == 0, H % 8 == 0), 6 = 3x3 halo kernel for cin, cout % 128 == 0, weights
-                                              in the bn_tile = 128 packing of kernel 0 (W % 32 == 0, H % 8 == 0); 1 is retired */
+                                              in the bn_tile = 128 packing of kernel 0 (W % 32 == 0, H % 8 == 0), 7 = 64->128 3x3 STRIDE-2 halo kernel, filter bank in
+                                              registers (output W % 32 == 0, H % 4 == 0; weights fp16 [9 taps][2 k halves][8 tiles][64 lanes][8]); 1 is retired */
     int bn_tile;                           /* MFMA: cout tile the weights were packed for (16/32/64/128) */
     int out_nchw_f32;                      /* 0, or 1..4 = index+1 into rtm3d_forward's out_logits[] */
     int out_H, out_W;                      /* only for out_nchw_f32 */

@@ -159,6 +159,8 @@ bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
 bool conv64_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_conv64_root(const ConvKArgs& a, const RootKArgs& r, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
+bool conv64s2_halo_supported(const ConvKArgs& a, int groups);
+hipError_t launch_conv64s2_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 bool conv128_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv128_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_conv_smallc(const ConvKArgs& a, hipStream_t s);

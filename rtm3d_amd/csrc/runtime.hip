@@ -27,7 +27,7 @@ struct Tensor {
     size_t elems;   // padded elements (without guards)
 };
 
-enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV64_ROOT, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX, OP_PATCH_MASK };
+enum OpKind { OP_CONV_MFMA, OP_CONV_MFMA256, OP_CONV64_HALO, OP_CONV64_ROOT, OP_CONV64S2_HALO, OP_CONV128_HALO, OP_STEM_FUSED, OP_CONV32S2_FUSED, OP_CONV_SMALLC, OP_INPUT4, OP_HEADOUT, OP_MAXPOOL, OP_SOFTMAX, OP_PATCH_MASK };
 
 struct Op {
     OpKind kind;
@@ -305,6 +305,17 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[0].w_off = 0; a.g[0].bias_off = 0;
         op.kind = OP_CONV64_HALO; op.bn_tile = 64; op.ticket_slot = ctx->ticket_slots_used++;
         op.name = "conv3x3_c64_halo";
+    } else if (d->kernel == 7) {
+        // 64 -> 128 channel 3x3 STRIDE-2 halo kernel with the filter bank in registers (conv64s2_halo.hip)
+        if (d->out_nchw_f32 || res) RT_FAIL("op_conv(conv64s2): NCHW output / residual unsupported");
+        a.cpt = 1; a.ksteps = 9; a.MT = 0; a.NT = 1;
+        if (!conv64s2_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv64s2): needs one 64->128 3x3 stride-2 conv onto a map with W %% 32 == 0, H %% 4 == 0 (input border >= 1)");
+        if (wbytes != (size_t)9 * 64 * 128 * sizeof(f16) || bbytes != 128 * sizeof(float)) RT_FAIL("op_conv(conv64s2): weight/bias blob size mismatch");
+        if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv(conv64s2): out of ticket counters");
+        if (ensure_tile_ctr(ctx)) return 1;
+        a.g[0].w_off = 0; a.g[0].bias_off = 0;
+        op.kind = OP_CONV64S2_HALO; op.bn_tile = 128; op.ticket_slot = ctx->ticket_slots_used++;
+        op.name = "conv3x3s2_c64_halo";
     } else if (d->kernel == 6) {
         // 3x3 halo kernel for multiples of 128 channels, weights streamed through an LDS ring (conv128_halo.hip); the weight
         // blob is the generic kernel's packing for 128-channel tiles
@@ -378,7 +389,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         op.kind = OP_CONV_SMALLC;
         op.name = d->cin == 4 ? "stem7x7_regmfma" : "conv_smallc_regmfma";
     } else {
-        RT_FAIL("op_conv: unknown kernel %d (0 = MFMA 128-px tile, 2 = MFMA 256x256 tile, 3 = register-direct MFMA)", d->kernel);
+        RT_FAIL("op_conv: unknown kernel %d (0 = MFMA 128-px tile, 2 = MFMA 256x256 tile, 3 = register-direct MFMA, 5 / 6 / 7 = halo kernels)", d->kernel);
     }
     if (d->softmax_stat_slot >= 0 && stat_slot < 0) RT_FAIL("op_conv: softmax_stat_slot needs kernel = 2");
     if (stat_slot >= 0) {
@@ -675,6 +686,7 @@ static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, f
         }
         case OP_CONV_MFMA256: e = launch_conv_mfma256(op.conv, op.groups, ctx->tile_ctr, op.stat_out, s); break;
         case OP_CONV64_HALO: e = launch_conv64_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
+        case OP_CONV64S2_HALO: e = launch_conv64s2_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV64_ROOT: e = launch_conv64_root(op.conv, op.root, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_CONV128_HALO: e = launch_conv128_halo(op.conv, ctx->n_cus, ctx->tile_ctr + 8 + op.ticket_slot, s); break;
         case OP_STEM_FUSED: {

@@ -558,6 +558,7 @@ def conv64_eligible(op):
 
 BN_TILE_OVERRIDE = {}     # DIAGNOSTIC (bench.py --bn-tile): op name -> output-channel tile of the 128-pixel kernel, for A/B runs
 USE_CONV128 = True
+USE_CONV64S2 = os.environ.get('RTM3D_CONV64S2', '1') != '0'   # 64 -> 128 stride-2 entry convs on conv64s2_halo.hip (A/B switch)
 C128_MIN_TILES = 256     # at least one 8 x 32-pixel tile per CU, else the small-launch kernels of conv_mfma.hip do better (ResNet-18 bs=8, 240 tiles: 3.87 ms per step on this kernel against 3.76)
 
 
@@ -569,6 +570,21 @@ def conv128_eligible(op, B):
     return (op['cin'] == 128 and op['cout'] == 128 and op['groups'] == 1 and op['in_stride'] == 1 and op['out_scale'] == 1
             and not op['out_nchw'] and list(op['taps'][0]) == taps3 and op['Hm'] % 8 == 0 and op['Wm'] % 32 == 0
             and B * (op['Hm'] // 8) * (op['Wm'] // 32) >= C128_MIN_TILES)
+
+
+def conv64s2_eligible(op):
+    """3x3 / STRIDE 2 / dilation 1 / 64 -> 128 channels onto a map that 4 x 32 pixel tiles cover: conv64s2_halo.hip."""
+    taps3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    return (USE_CONV64S2 and op['cin'] == 64 and op['cout'] == 128 and op['groups'] == 1 and op['in_stride'] == 2 and op['out_scale'] == 1
+            and not op['out_nchw'] and op['res'][0] is None and list(op['taps'][0]) == taps3 and op['Hm'] % 4 == 0 and op['Wm'] % 32 == 0
+            and 'tap_dc' not in op)
+
+
+def pack_conv64s2_weights(wt):
+    """wt: (9, 128, 64) fp32 [tap][cout][cin] -> fp16 [tap][k half][16-channel tile of 8][lane = fk*16 + row][8] (conv64s2_halo.hip)."""
+    w = wt.reshape(9, 8, 16, 2, 4, 8)                 # tap, ct, row, kk, fk, j
+    w = w.transpose(0, 3, 1, 4, 2, 5)                 # tap, kk, ct, fk, row, j
+    return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
 
 
 def pack_conv64_weights(wt):
@@ -939,9 +955,15 @@ class RealizedPlan(object):
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
         if variant is None:
-            variant = (5 if conv64_eligible(op) else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)
+            variant = (5 if conv64_eligible(op) else 7 if conv64s2_eligible(op) and self.plan.B * (op['Hm'] // 4) * (op['Wm'] // 32) >= 64
+                       else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)
                        else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'], len(op['taps'][0]), op['in_stride']))
-        if variant == 6:
+        if variant == 7:
+            assert conv64s2_eligible(op), op['name']
+            d.kernel, d.bn_tile = 7, 128
+            d.w_blob = self._blob(self._packed(op, 0, 'c64s2', 0, lambda: pack_conv64s2_weights(op['w'][0])))
+            d.bias_blob = self._blob(np.ascontiguousarray(op['bias'][0], np.float32))
+        elif variant == 6:
             d.kernel, d.bn_tile = 6, 128
             d.w_blob = self._blob(self._packed(op, 0, 'mfma', 128, lambda: pack_mfma_weights(op['w'][0], 128)[0]))
             d.bias_blob = self._blob(np.ascontiguousarray(op['bias'][0], np.float32))

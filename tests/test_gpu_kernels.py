@@ -58,6 +58,10 @@ CONV_CASES = [
     (1, 8, 32, 128, 128, 3, 1, 1, True, False, 6, 0),       # conv128 halo: a single tile
     (8, 96, 160, 128, 128, 3, 1, 1, True, True, 6, 0),      # conv128 halo: 480 tiles on 256 workgroups (ticket hand-out)
     (2, 16, 64, 256, 256, 3, 1, 1, True, True, 6, 0),       # conv128 halo: two channel tiles per pixel tile, 4 input chunks, residual
+    (2, 16, 64, 64, 128, 3, 2, 1, True, False, 7, 0),       # conv64s2 halo: 8 x 32 output map, 4 tiles
+    (3, 24, 128, 64, 128, 3, 2, 1, False, False, 7, 64),    # conv64s2 halo: no ReLU, input slice of a wider tensor, 18 tiles
+    (1, 8, 64, 64, 128, 3, 2, 1, True, False, 7, 0),        # conv64s2 halo: a single tile
+    (8, 96, 320, 64, 128, 3, 2, 1, True, False, 7, 0),      # conv64s2 halo: 480 tiles on 256 workgroups (ticket hand-out)
     (2, 16, 24, 16, 16, 3, 1, 1, True, False, 3, 0),        # smallc 16->16
     (2, 16, 24, 16, 32, 3, 2, 1, True, False, 3, 0),        # smallc 16->32 s2
     (1, 18, 26, 32, 64, 3, 2, 1, True, False, 3, 0),        # smallc 32->64 s2
