@@ -90,6 +90,11 @@ typedef struct rtm3d_conv_desc {
     int out_oy[RTM3D_MAX_GROUPS], out_ox[RTM3D_MAX_GROUPS];
     int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
     int tap_dc[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS]; /* channel offset of the tap relative to in_coff (multiple of 8; kernels 0 and 2 only) */
+    int s2d_tensor, s2d_coff;              /* s2d_tensor >= 0 (kernel 0, groups 1, out_scale 1, even output height / width): the output is
+                                              written a SECOND time in space-to-depth layout - pixel (y, x) to pixel (y >> 1, x >> 1), channels
+                                              s2d_coff + ((y & 1) * 2 + (x & 1)) * cout + c of the half-resolution s2d_tensor - so that the neck
+                                              can read the feature map from the grid of its transposed conv's input (plan.py: _neck_up_folds).
+                                              NOTE for callers that zero-initialise the struct: 0 is a valid tensor id, set -1 for "none". */
     int relu;
     int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
     int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 2 = MFMA 256x256 tile
@@ -135,10 +140,13 @@ int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv
  * with lane = fk * 16 + row, element j = root weight [tile * 16 + row][s * 32 + (j >> 2) * 16 + fk * 4 + (j & 3)] over the
  * concatenated input [x2 | x1] (the K order in which the conv's accumulator fragments are handed to the root's MFMAs);
  * fp32 biases [64] with BN folded.  Same result as the rtm3d_op_conv / rtm3d_op_maxpool launches it replaces up to fp32
- * summation order.                                                                                                        */
+ * summation order.  s2d_tensor >= 0: `out` is written a second time in space-to-depth layout - pixel (y, x) to half-resolution
+ * pixel (y >> 1, x >> 1), channels s2d_coff + ((y & 1) * 2 + (x & 1)) * 64 + c of s2d_tensor - which lets the neck read the
+ * feature map at the resolution of the transposed conv's INPUT grid (rtm3d_amd/plan.py: RealizedPlan._neck_up_folds).        */
 int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,
                          int w_conv_blob, int b_conv_blob, int w_root_blob, int b_root_blob,
-                         int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff);
+                         int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff,
+                         int s2d_tensor, int s2d_coff);
 
 /* The four final 3x3 convolutions of the heads in one launch (models/nets/header.py:17,27,32,37):
  * input = the nheads x 256-channel tensor written by the grouped head conv (nheads = 4, or 2 for the

@@ -27,6 +27,7 @@ class ConvDesc(ctypes.Structure):
         ('out_oy', c_int * MAX_GROUPS), ('out_ox', c_int * MAX_GROUPS),
         ('tap_dy', (c_int * MAX_TAPS) * MAX_GROUPS), ('tap_dx', (c_int * MAX_TAPS) * MAX_GROUPS),
         ('tap_dc', (c_int * MAX_TAPS) * MAX_GROUPS),
+        ('s2d_tensor', c_int), ('s2d_coff', c_int),
         ('relu', c_int),
         ('w_blob', c_int), ('bias_blob', c_int),
         ('kernel', c_int), ('bn_tile', c_int),
@@ -68,7 +69,7 @@ SIGNATURES = {
     'rtm3d_op_conv': (c_int, [c_void_p, ctypes.POINTER(ConvDesc)]),
     'rtm3d_op_stem_fused': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_conv32s2_fused': (c_int, [c_void_p] + [c_int] * 10),
-    'rtm3d_op_conv64_root': (c_int, [c_void_p] + [c_int] * 14),
+    'rtm3d_op_conv64_root': (c_int, [c_void_p] + [c_int] * 16),
     'rtm3d_op_headout': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_patch_mask': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_gather_peak_patches': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -54,6 +54,10 @@ struct ConvKArgs {
     float* slab;                  // split-K (conv_mfma_deep_kernel): fp32 partial tiles [split][group][tile][128 x BN], else null
     int ksplit;                   // number of K ranges (grid.z); 0 / 1 = off
     int deep;                     // 1: small launch, runs on conv_mfma_deep_kernel (4-slot LDS ring, optional split-K)
+    // second copy of the output in SPACE-TO-DEPTH layout (conv_mfma.hip epilogue only), or null: pixel (y, x) -> half-resolution
+    // pixel (y >> 1, x >> 1), channels s_coff + ((y & 1) * 2 + (x & 1)) * cout + c
+    f16* s2d;
+    int s_Hp, s_Wp, s_C, s_P, s_coff;
     ConvGroupArgs g[RT_MAX_GROUPS];
 };
 
@@ -138,6 +142,8 @@ struct RootKArgs {
     int o_Hp, o_Wp, o_C, o_P, o_coff;
     f16* pool;              // 2x2 / stride 2 max-pool of the root output (64 channels at p_coff, half resolution), or null
     int p_Hp, p_Wp, p_C, p_P, p_coff;
+    f16* s2d;               // second copy of the root output in SPACE-TO-DEPTH layout, or null: pixel (y, x) -> half-resolution pixel
+    int s_Hp, s_Wp, s_C, s_P, s_coff;      // (y >> 1, x >> 1), channels s_coff + ((y & 1) * 2 + (x & 1)) * 64 + c
     int relu;
 };
 

@@ -2,6 +2,7 @@
 //   x2   = ReLU(BN(conv3x3(t)) + x1)                    tree2's second block conv + residual (dla.py:86-100)
 //   out  = ReLU(BN(conv1x1(cat[x2, x1])))               the tree's root (dla.py:233-241, root_residual = False)
 //   pool = max_pool2d(out, 2, 2)                        the NEXT level's `downsample` (dla.py:170-172,190), optional
+//   s2d  = out in space-to-depth layout                 optional second copy for the neck (plan.py: _neck_up_folds)
 // As three launches these are HBM-bound (conv 0.093 ms reading t and x1 and writing x2, root 0.081 ms reading x2 and x1
 // again and writing out, pool 0.029 ms reading out again: 7.25 passes over a 126 MB map at bs=32).  Fused, x2 never
 // leaves the registers, x1 is read once and the pooled map is written from the root's output registers: 3.25 passes.
@@ -45,7 +46,7 @@ __device__ __forceinline__ uint32_t cr_pkmax(uint32_t x, uint32_t y) {
     return r;
 }
 
-template <int POOL>
+template <int POOL, int S2D>
 __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, const RootKArgs r, unsigned int* ticket_ctr, const int single) {
     __shared__ __attribute__((aligned(128))) f16 lds[(2 * C64_BUF_PIECES + CR_W_PIECES + CR_X_PIECES) * 8];
     __shared__ __attribute__((aligned(16))) float sbias[128];      // [0, 64): conv bias, [64, 128): root bias
@@ -127,13 +128,10 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
                    ck_p = (uint32_t)((((frow + 2) ^ fk) & 7) << 4);
     const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
     const f16x4 lo4 = {lo, lo, lo, lo};
-    const int so = (fk & 1) * 16 + (fk >> 1) * 8;
     const uint32_t lane_roff = (uint32_t)(frow * a.res_C + fk * 4);
     // exchange slots: this wave writes [wave][slot][lane], reads [wave ^ 1][slot][lane]; slot = q (x2), 2 + q (x1)
-    const uint32_t xc_wr = lds_xc + (uint32_t)((wave * 256 + lane) * 16), xc_rd = lds_xc + (uint32_t)(((wave ^ 1) * 256 + lane) * 16);
     // root A fragments [ct][s][lane]: K-step s of the packed weights = cat channels s*32 .. s*32+31 ([x2 | x1]); this wave
     // multiplies its own halves (s = wc, 2 + wc) first, then the partner's
-    const uint32_t rw_lane = lds_rw + (uint32_t)(lane * 16);
 
     stage(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -213,6 +211,14 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
             bx1[p] = (f16x8){rv[p][0][0], rv[p][0][1], rv[p][0][2], rv[p][0][3], rv[p][1][0], rv[p][1][1], rv[p][1][2], rv[p][1][3]};
         }
         // keep fragments 2q + wc (columns wc*16.., rows 2wp + q), hand fragments 2q + 1 - wc to the partner
+        // (lane-derived LDS / store offsets of the root phase are recomputed per tile from an opaque copy of the lane id: the kernel
+        // sits at the 256-register budget of two waves per SIMD, and loop-invariant values would be carried across the conv)
+        uint32_t l2 = (uint32_t)lane;
+        asm volatile("" : "+v"(l2));
+        const uint32_t xc_wr = lds_xc + (uint32_t)(wave * 256 * 16) + l2 * 16, xc_rd = lds_xc + (uint32_t)((wave ^ 1) * 256 * 16) + l2 * 16;
+        const uint32_t rw_lane = lds_rw + l2 * 16;
+        const uint32_t fr2 = l2 & 15, fk2 = l2 >> 4;
+        const uint32_t so2 = (fk2 & 1) * 16 + (fk2 >> 1) * 8;
         f16x8 kx2[2], kx1[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -233,14 +239,15 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
         }
 
         // ---- root: out[64 channels] of 2 x 16 pixels, two output-channel tiles at a time
-        const size_t opix0 = ((size_t)(n * r.o_Hp + ty * 8 + 2 * wp + r.o_P) * r.o_Wp + tx * 32 + wc * 16 + frow + r.o_P) * r.o_C + r.o_coff;
+        f16* const obase = r.out + ((size_t)(n * r.o_Hp + ty * 8 + 2 * wp + r.o_P) * r.o_Wp + tx * 32 + wc * 16 + r.o_P) * r.o_C + r.o_coff;   // wave-uniform
+        const uint32_t olane = fr2 * (uint32_t)r.o_C + so2;
         uint32_t pl[2][4];                          // packed 2x2-max candidates: [channel pair-of-tiles][dword]
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
             f32x4 ra[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const f32x4 bv = *(const f32x4*)(sbias + 64 + (cp * 2 + c) * 16 + fk * 4);
+                const f32x4 bv = *(const f32x4*)(sbias + 64 + (cp * 2 + c) * 16 + fk2 * 4);
                 ra[c][0] = bv; ra[c][1] = bv;
             }
 #pragma unroll
@@ -272,7 +279,14 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
                 o[q][0] = s0[0]; o[q][1] = s1[0]; o[q][2] = s0[1]; o[q][3] = s1[1];
                 const u32x4 ov = {o[q][0], o[q][1], o[q][2], o[q][3]};
-                *(u32x4*)(r.out + opix0 + (size_t)q * r.o_Wp * r.o_C + cp * 32 + so) = ov;
+                *(u32x4*)(obase + (size_t)(q * r.o_Wp * r.o_C + cp * 32) + olane) = ov;
+                if (S2D) {
+                    // space-to-depth copy: this lane's pixel (row 2 wp + q, column wc * 16 + frow of the tile) has phase (q, frow & 1);
+                    // wave-uniform base + a 32-bit lane offset recomputed here (the kernel has no register to keep it in)
+                    const uint32_t loff = (fr2 >> 1) * (uint32_t)r.s_C + (fr2 & 1) * 64 + so2;
+                    const f16* sb = r.s2d + ((size_t)(n * r.s_Hp + ty * 4 + wp + r.s_P) * r.s_Wp + tx * 16 + wc * 8 + r.s_P) * r.s_C + r.s_coff + q * 128 + cp * 32;
+                    *(u32x4*)((f16*)sb + loff) = ov;
+                }
             }
             if (POOL) {
 #pragma unroll
@@ -284,19 +298,18 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
             uint32_t m[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t mine = (frow & 1) ? pl[1][e] : pl[0][e];
-                const uint32_t give = (frow & 1) ? pl[0][e] : pl[1][e];     // what the neighbour wants from me
+                const uint32_t mine = (fr2 & 1) ? pl[1][e] : pl[0][e];
+                const uint32_t give = (fr2 & 1) ? pl[0][e] : pl[1][e];     // what the neighbour wants from me
                 const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
                 m[e] = cr_pkmax(mine, got);
             }
-            const size_t ppix = ((size_t)(n * r.p_Hp + ty * 4 + wp + r.p_P) * r.p_Wp + tx * 16 + wc * 8 + (frow >> 1) + r.p_P) * r.p_C + r.p_coff;
+            f16* const pbase = r.pool + ((size_t)(n * r.p_Hp + ty * 4 + wp + r.p_P) * r.p_Wp + tx * 16 + wc * 8 + r.p_P) * r.p_C + r.p_coff;   // wave-uniform
             const u32x4 pv = {m[0], m[1], m[2], m[3]};
-            *(u32x4*)(r.pool + ppix + (frow & 1) * 32 + so) = pv;
+            *(u32x4*)(pbase + ((fr2 >> 1) * (uint32_t)r.p_C + (fr2 & 1) * 32 + so2)) = pv;
         }
         if (!more) break;
         // the next tile's halo (issued before this tile's loads and stores) must have landed; the stores may stay in flight
-        if (POOL) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + POOL + 4 * S2D) : "memory");
         cur = nxt; nxt = nn;
         par ^= 1;
         ++it;
@@ -308,7 +321,10 @@ bool conv64_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv64_root(const ConvKArgs& a, const RootKArgs& r, int cu_count, unsigned int* ticket_ctr, hipStream_t s) {
     const int total = (a.M / a.HmWm) * (a.Wm >> 5) * ((a.HmWm / a.Wm) >> 3);
     const int grid = cu_count < total ? cu_count : total;
-    if (r.pool) hipLaunchKernelGGL(conv64_root_kernel<1>, dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, total <= cu_count ? 1 : 0);
-    else hipLaunchKernelGGL(conv64_root_kernel<0>, dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, total <= cu_count ? 1 : 0);
+    const int single = total <= cu_count ? 1 : 0;
+    if (r.pool && r.s2d) hipLaunchKernelGGL((conv64_root_kernel<1, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.pool) hipLaunchKernelGGL((conv64_root_kernel<1, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.s2d) hipLaunchKernelGGL((conv64_root_kernel<0, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else hipLaunchKernelGGL((conv64_root_kernel<0, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
     return hipGetLastError();
 }

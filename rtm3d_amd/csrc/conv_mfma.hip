@@ -34,7 +34,7 @@ __device__ __forceinline__ void store_nhwc_tile(const ConvKArgs& a, const ConvGr
     for (int c = 0; c < TC; ++c) bv[c] = *(const f32x4*)(a.bias + g.bias_off + cw + c * 16 + fk * 4);
     const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
     const f16x4 lo4 = {lo, lo, lo, lo};
-    size_t opix[TP];
+    size_t opix[TP], spix[TP];
     f16x4 rv[TP][TC];
 #pragma unroll
     for (int p = 0; p < TP; ++p) {
@@ -45,6 +45,9 @@ __device__ __forceinline__ void store_nhwc_tile(const ConvKArgs& a, const ConvGr
         const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
         const int oy = y * a.out_scale + g.out_oy, ox = x * a.out_scale + g.out_ox;
         opix[p] = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + cw;
+        spix[p] = 0;
+        if (a.s2d)      // space-to-depth copy (the neck reads the feature at the resolution of its transposed conv's input grid)
+            spix[p] = ((size_t)(n * a.s_Hp + (oy >> 1) + a.s_P) * a.s_Wp + (ox >> 1) + a.s_P) * a.s_C + a.s_coff + ((oy & 1) * 2 + (ox & 1)) * a.cout + cw;
         if (RES) {
             const f16* rp = a.res + ((size_t)(n * a.res_Hp + oy + a.res_P) * a.res_Wp + ox + a.res_P) * a.res_C + g.res_coff + cw + fk * 4;
 #pragma unroll
@@ -76,12 +79,18 @@ __device__ __forceinline__ void store_nhwc_tile(const ConvKArgs& a, const ConvGr
                 const auto s0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                 const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                if (cw + c * 16 + so < a.cout) *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;
+                if (cw + c * 16 + so < a.cout) {
+                    *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;
+                    if (a.s2d) *(u32x4*)(a.s2d + spix[p] + c * 16 + so) = o;
+                }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < TC; ++c)
-                if (cw + c * 16 + fk * 4 < a.cout) *(f16x4*)((f16*)a.out + opix[p] + c * 16 + fk * 4) = h[c];
+                if (cw + c * 16 + fk * 4 < a.cout) {
+                    *(f16x4*)((f16*)a.out + opix[p] + c * 16 + fk * 4) = h[c];
+                    if (a.s2d) *(f16x4*)(a.s2d + spix[p] + c * 16 + fk * 4) = h[c];
+                }
         }
     }
 }

@@ -277,11 +277,22 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[g].in_coff = d->in_coff[g]; a.g[g].out_coff = d->out_coff[g]; a.g[g].res_coff = d->res_coff[g];
         a.g[g].out_oy = d->out_oy[g]; a.g[g].out_ox = d->out_ox[g];
     }
+    if (d->s2d_tensor >= 0) {
+        Tensor* s2 = get_tensor(ctx, d->s2d_tensor);
+        if (!s2 || !out) RT_FAIL("op_conv: bad space-to-depth tensor %d", d->s2d_tensor);
+        if (d->kernel != 0 || d->groups != 1 || d->out_scale != 1 || d->out_oy[0] || d->out_ox[0] || (d->Hm & 1) || (d->Wm & 1) || (d->cout % 8))
+            RT_FAIL("op_conv: the space-to-depth copy needs kernel 0, one group, out_scale 1 and an even output height / width");
+        if (s2->B != in->B || s2->H * 2 != d->Hm || s2->W * 2 != d->Wm || d->s2d_coff < 0 || d->s2d_coff + 4 * d->cout > s2->C || (d->s2d_coff % 8))
+            RT_FAIL("op_conv: space-to-depth slice mismatch (half resolution, 4 x cout channels)");
+        if (s2 == out || s2 == in || s2 == res) RT_FAIL("op_conv: the space-to-depth copy aliases an operand");
+        a.s2d = s2->base; a.s_Hp = s2->Hp; a.s_Wp = s2->Wp; a.s_C = s2->C; a.s_P = s2->P; a.s_coff = d->s2d_coff;
+    }
     op.groups = d->groups; op.epi_nchw = d->out_nchw_f32 ? 1 : 0; op.out_slot = d->out_nchw_f32 - 1;
     int stat_slot = -1;
     const double M = (double)a.M;
     op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
-    op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0);
+    op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0)
+               + (d->s2d_tensor >= 0 ? 2.0 * M * d->cout : 0.0);
     if (d->kernel == 2) {
         if (d->cin % 64 || d->cout % 256 || d->out_nchw_f32) RT_FAIL("op_conv(mfma256): needs cin %% 64 == 0, cout %% 256 == 0, NHWC output (cin=%d cout=%d)", d->cin, d->cout);
         a.cpt = d->cin / 64; a.ksteps = d->ntaps * a.cpt;
@@ -504,12 +515,19 @@ extern "C" int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_cof
 
 extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,
                                     int w_conv_blob, int b_conv_blob, int w_root_blob, int b_root_blob,
-                                    int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff) {
+                                    int out_tensor, int out_coff, int root_relu, int pool_tensor, int pool_coff,
+                                    int s2d_tensor, int s2d_coff) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     Tensor* res = ctx ? get_tensor(ctx, res_tensor) : nullptr;
     Tensor* out = ctx ? get_tensor(ctx, out_tensor) : nullptr;
     Tensor* pool = ctx && pool_tensor >= 0 ? get_tensor(ctx, pool_tensor) : nullptr;
-    if (!in || !res || !out || (pool_tensor >= 0 && !pool)) RT_FAIL("op_conv64_root: bad tensors");
+    Tensor* s2d = ctx && s2d_tensor >= 0 ? get_tensor(ctx, s2d_tensor) : nullptr;
+    if (!in || !res || !out || (pool_tensor >= 0 && !pool) || (s2d_tensor >= 0 && !s2d)) RT_FAIL("op_conv64_root: bad tensors");
+    if (s2d) {
+        if (s2d->H * 2 != in->H || s2d->W * 2 != in->W || s2d->B != in->B || s2d_coff < 0 || s2d_coff + 256 > s2d->C || (s2d_coff % 8))
+            RT_FAIL("op_conv64_root: space-to-depth output slice mismatch (half resolution, 4 x 64 channels)");
+        if (s2d == out || s2d == res || s2d == in) RT_FAIL("op_conv64_root: the space-to-depth copy aliases an operand");
+    }
     if (in->P < 1 || in_coff < 0 || in_coff + 64 > in->C || (in_coff % 8)) RT_FAIL("op_conv64_root: input slice mismatch (64 channels, border >= 1)");
     if (in->H % 8 || in->W % 32) RT_FAIL("op_conv64_root: needs H %% 8 == 0 and W %% 32 == 0 (got %dx%d)", in->H, in->W);
     for (Tensor* t : {res, out})
@@ -545,11 +563,13 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
     r.w = w1; r.bias = b1; r.out = out->base; r.o_Hp = out->Hp; r.o_Wp = out->Wp; r.o_C = out->C; r.o_P = out->P; r.o_coff = out_coff;
     r.relu = root_relu ? 1 : 0;
     if (pool) { r.pool = pool->base; r.p_Hp = pool->Hp; r.p_Wp = pool->Wp; r.p_C = pool->C; r.p_P = pool->P; r.p_coff = pool_coff; }
+    if (s2d) { r.s2d = s2d->base; r.s_Hp = s2d->Hp; r.s_Wp = s2d->Wp; r.s_C = s2d->C; r.s_P = s2d->P; r.s_coff = s2d_coff; }
     op.kind = OP_CONV64_ROOT; op.groups = 1; op.bn_tile = 64; op.epi_nchw = 0; op.out_slot = -1; op.ticket_slot = ctx->ticket_slots_used++;
     op.name = pool ? "conv3x3_c64+root1x1+pool_fused" : "conv3x3_c64+root1x1_fused";
+    if (s2d) op.name += "+s2d";
     const double M = (double)a.M;
     op.flops = 2.0 * M * (9.0 * 64 * 64 + 128.0 * 64);
-    op.bytes = 2.0 * M * (64.0 * 3 + (pool ? 16.0 : 0.0));      // conv input, x1, root output (+ the pooled map)
+    op.bytes = 2.0 * M * (64.0 * 3 + (pool ? 16.0 : 0.0) + (s2d ? 64.0 : 0.0));      // conv input, x1, root output (+ the pooled map, + the second copy)
     ctx->ops.push_back(op);
     return 0;
 }

@@ -28,6 +28,7 @@ FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 s
 FUSE_LEVEL_TAIL = True    # DLA level2 tail: tree2.conv2 + residual, the root 1x1 and the next level's 2x2 max-pool in one launch (conv64_root.hip)
 FOLD_PROJECT = True       # DLA levels 3-5: a block's `project` 1x1 (on the pooled input) as extra K-steps of the block's second conv
 FOLD_PROJECT_C128 = os.environ.get('RTM3D_FOLD_C128', '1') != '0'  # ... also where that conv would otherwise take conv128_halo (level3), which has no one-tap chunk: generic kernel
+FOLD_NECK_UP = os.environ.get('RTM3D_FOLD_NECK_UP', '1') != '0'   # neck: proj+head 1x1 composed INTO the transposed conv in front of it (RealizedPlan._neck_up_folds)
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
 
@@ -595,6 +596,12 @@ def pack_conv64_weights(wt):
     return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
 
 
+def A_bias(J, D):
+    """A_up applied to the transposed conv's own bias (zero for the reference's UpSample, models/nets/module.py:9: bias=False)."""
+    A_up = J['w'][0][0][:, :256].astype(np.float64)
+    return A_up @ D['bias'][0].astype(np.float64)
+
+
 def pack_root64_weights(wt):
     """wt: (64, 128) fp32 [cout][cat channel] (cat = [x2 | x1]) -> fp16 [4 output tiles][4 K-steps][lane = fk*16 + row][8] for
     conv64_root.hip: element j of lane (fk, row) in K-step s is cat channel s*32 + (j >> 2)*16 + fk*4 + (j & 3) - the order in
@@ -631,17 +638,22 @@ class RealizedPlan(object):
         self.ctx = ctx
         self._keep = []
         self.tids = []
-        for t in plan.tensors:
-            tid = ctypes.c_int()
-            _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'], t['pad'], ctypes.byref(tid)), 'tensor_create')
-            self.tids.append(tid.value)
         self._stat_slots = self._softmax_stat_producers()
+        tail = self._level_tail_chains() if FUSE_LEVEL_TAIL else {}
+        nfold = self._neck_up_folds(tail) if FOLD_NECK_UP else []
+        widen = {f['hs'].tid: 4 * f['Cf'] for f in nfold}    # device tensors that also hold a space-to-depth copy of a backbone feature
+        self._s2d_for = {f['feat']: (f['hs'], plan.tensors[f['hs'].tid]['C']) for f in nfold if 'feat' in f}
+        for i, t in enumerate(plan.tensors):
+            tid = ctypes.c_int()
+            _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'] + widen.get(i, 0), t['pad'], ctypes.byref(tid)), 'tensor_create')
+            self.tids.append(tid.value)
         self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
         entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
-        tail = self._level_tail_chains() if FUSE_LEVEL_TAIL else {}
         folds = self._project_folds() if FOLD_PROJECT else {}
-        skip = set(folds.values())
+        skip = set(folds.values()) | {f['up'] for f in nfold}
+        s2d_of = {f['tail']: f for f in nfold if 'tail' in f}   # conv64_root launch -> the fold its second (space-to-depth) output feeds
+        neck_by = {f['pj']: f for f in nfold}
         folded_by = {}
         for c2k, pjk in folds.items():
             folded_by[c2k] = self._folded_conv(plan.ops[c2k], plan.ops[pjk])
@@ -664,14 +676,114 @@ class RealizedPlan(object):
             if k in tail:
                 root = plan.ops[tail[k][0]]
                 pool = plan.ops[tail[k][1]] if len(tail[k]) > 1 else None
-                self._op_conv64_root(op, root, pool)
-                self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else ''))
+                f = s2d_of.get(k)
+                self._op_conv64_root(op, root, pool, s2d=(f['hs'], plan.tensors[f['hs'].tid]['C']) if f else None)
+                self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else '') + ('+s2d' if f else ''))
                 skip.update(tail[k])
                 continue
             if k in folded_by:
                 op = folded_by[k]
+            if k in neck_by:
+                op = self._neck_fold_conv(neck_by[k])
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
+
+    def _neck_up_folds(self, tail):
+        """Neck (models/nets/keypoint_fpn_fusion.py:35-46): x[i-1] = head(proj(cat[up(h), feat])) with up = ConvTranspose2d without
+        bias or non-linearity and proj∘head already composed into ONE 1x1 conv A = [A_up | A_f]:
+            out = A_up (up h) + A_f feat + b  =  up'(h) + A_f feat + b,     up' = the transposed conv with weights A_up W (per tap).
+        Run as ONE launch over the transposed conv's input grid, the 1x1's share of the FEATURE map is Cf / 64 more K-steps per
+        sub-pixel phase - provided the feature pixel (2y + py, 2x + px) can be addressed from grid position (y, x): the feature's
+        producer writes a second, space-to-depth copy into spare channels of the tensor that holds h (rtm3d_conv_desc.tap_dc names
+        them).  The `up` map (0.5 GB at bs=32 for the last level) is never written or read, one launch per level goes away.  (Round 2
+        tried the same algebra with the feature term as an epilogue residual of the transposed conv: slower.  Here it is K-steps.)
+        Matches (deconv D onto channels [0, 256) of T; 1x1 J over all of T = [up | feat]) where feat is written by the root of a
+        fused level tail (conv64_root.hip) or by a plain conv that can run on the 128-pixel kernel (both can emit the copy).
+        Returns [{'up', 'pj', 'hs', 'Cf', 'tail' | 'feat'}]."""
+        P = self.plan
+        out = []
+        for kj, J in enumerate(P.ops):
+            if (J['op'] != 'conv' or J['groups'] != 1 or list(J['taps'][0]) != [(0, 0)] or J['in_stride'] != 1 or J['out_scale'] != 1 or J['relu']
+                    or J['res'][0] is not None or J['out_nchw'] or J['cout'] != 256 or J['cin'] <= 256 or (J['cin'] - 256) % 64 or J.get('variant') is not None):
+                continue
+            T, Cf = J['inp'][0], J['cin'] - 256
+            if T.coff != 0 or P.tensors[T.tid]['C'] != J['cin']:
+                continue
+            ups = [k for k in range(kj) if P.ops[k]['op'] == 'conv' and P.ops[k]['groups'] == 4 and P.ops[k]['out_scale'] == 2
+                   and all(o is not None and o.tid == T.tid and o.coff == 0 and o.C == 256 for o in P.ops[k]['out'])]
+            if len(ups) != 1:
+                continue
+            ku = ups[0]
+            D = P.ops[ku]
+            hs = D['inp'][0]
+            ok = (D['cin'] == 256 and D['cout'] == 256 and all(len(tp) == 4 for tp in D['taps']) and not D['relu'] and all(r is None for r in D['res'])
+                  and all(i.tid == hs.tid and i.coff == 0 for i in D['inp']) and hs.C == 256 and P.tensors[hs.tid]['C'] == 256
+                  and P.tensors[hs.tid]['pad'] >= 1 and self._stat_slots_of(ku) < 0 and D.get('variant') is None
+                  and (2 * D['Hm'], 2 * D['Wm']) == P.dims(J['out'][0]) and J['out'][0].tid not in (T.tid, hs.tid)
+                  and ((P.B * D['Hm'] * D['Wm'] + 255) // 256) * 4 >= V2_MIN_TILES and 16 + Cf // 64 <= _lib.MAX_TAPS)
+            # nothing but J reads the `up` slice
+            readers = [j for j, o in enumerate(P.ops) if j != ku and self._reads_slice(o, Slice(T.tid, 0, 256))]
+            ok = ok and readers == [kj]
+            # who writes the feature slice [256, 256 + Cf)
+            fold = {'up': ku, 'pj': kj, 'hs': hs, 'Cf': Cf}
+            if ok:
+                kt = [k for k, ch in tail.items() if (lambda o: o.tid == T.tid and o.coff == 256 and o.C == Cf)(P.ops[ch[0]]['out'][0])]
+                kf = [k for k, o in enumerate(P.ops) if o['op'] == 'conv' and o['groups'] == 1 and o['out_scale'] == 1 and not o['out_nchw'] and o['cin'] % 64 == 0
+                      and o['out'][0] is not None and o['out'][0].tid == T.tid and o['out'][0].coff == 256 and o['out'][0].C == Cf
+                      and o.get('variant') is None and o['Hm'] % 2 == 0 and o['Wm'] % 2 == 0 and o['cout'] % 16 == 0
+                      and not any(k in ch for ch in tail.values()) and k not in tail]
+                if len(kt) == 1 and Cf == 64 and kt[0] < ku:
+                    fold['tail'] = kt[0]
+                elif len(kf) == 1 and kf[0] < ku and not conv64_eligible(P.ops[kf[0]]) and not conv64s2_eligible(P.ops[kf[0]]):
+                    fold['feat'] = kf[0]
+                else:
+                    ok = False
+            # between the deconv's place and the 1x1's nothing may write h (the fused op runs at the 1x1's place)
+            if ok:
+                for j in range(ku + 1, kj):
+                    o = P.ops[j]
+                    outs = o['out'] if o['op'] == 'conv' else [o.get('out')] if o['op'] == 'maxpool' else [o.get('z_out')] if o['op'] == 'softmax' else []
+                    if any(t is not None and t.tid == hs.tid for t in outs):
+                        ok = False
+            if ok:
+                out.append(fold)
+        return out
+
+    def _stat_slots_of(self, k):
+        return self._stat_slots.get(k, -1)
+
+    def _neck_fold_conv(self, f):
+        P = self.plan
+        D, J, hs = P.ops[f['up']], P.ops[f['pj']], f['hs']
+        Cf, e = f['Cf'], f['Cf'] // 64
+
+        def make():
+            A = J['w'][0][0].astype(np.float64)                        # (256, 256 + Cf) = [A_up | A_f]
+            A_up, A_f = A[:, :256], A[:, 256:]
+            ws = []
+            for g in range(4):
+                wt = np.zeros((4 * 4 + e, 256, 64), np.float64)
+                for t in range(4):
+                    Wc = A_up @ D['w'][g][t].astype(np.float64)        # (cout, cin) of the composed tap
+                    for q in range(4):
+                        wt[t * 4 + q] = Wc[:, q * 64:(q + 1) * 64]
+                for q in range(e):
+                    wt[16 + q] = A_f[:, q * 64:(q + 1) * 64]
+                ws.append(wt)
+            return np.stack(ws, 0).astype(np.float32)
+        w = self.cache.get('neckfold:%s|%s' % (D['name'], J['name']), make) if self.cache is not None else make()
+        taps, dcs = [], []
+        base = P.tensors[hs.tid]['C']                                   # the space-to-depth copy sits behind h's own channels
+        for g in range(4):
+            py, px = D['out_off'][g]
+            tl = [(dy, dx) for (dy, dx) in D['taps'][g] for _ in range(4)] + [(0, 0)] * e
+            dc = [q * 64 for _ in range(4) for q in range(4)] + [base + (py * 2 + px) * Cf + q * 64 for q in range(e)]
+            taps.append(tl); dcs.append(dc)
+        bias = J['bias'][0].astype(np.float64) + A_bias(J, D)
+        return {'op': 'conv', 'name': D['name'] + '+' + J['name'], 'inp': [hs] * 4, 'out': [J['out'][0]] * 4, 'res': [None] * 4,
+                'Hm': D['Hm'], 'Wm': D['Wm'], 'in_stride': 1, 'out_scale': 2, 'cin': 64, 'cout': 256, 'groups': 4, 'taps': taps, 'tap_dc': dcs,
+                'out_off': list(D['out_off']), 'relu': False, 'w': w, 'bias': np.tile(bias.astype(np.float32)[None], (4, 1)), 'out_nchw': 0,
+                'out_hw': (2 * D['Hm'], 2 * D['Wm'])}
 
     def _project_folds(self):
         """{index of a block's second conv: index of the `project` 1x1 that produces its residual} where the 1x1 (no ReLU, stride
@@ -769,7 +881,7 @@ class RealizedPlan(object):
             return hit(op['z_in'], op['z_in'].C) or any(hit(u, u.C) for u in op['us'])
         return False
 
-    def _op_conv64_root(self, cv, rt, pool):
+    def _op_conv64_root(self, cv, rt, pool, s2d=None):
         f32 = lambda v: self._blob(np.ascontiguousarray(v, np.float32))
         x, x1, ro = cv['inp'][0], cv['res'][0], rt['out'][0]
         po = pool['out'] if pool is not None else None
@@ -778,7 +890,8 @@ class RealizedPlan(object):
         _lib.check(self.lib.rtm3d_op_conv64_root(self.ctx, self.tids[x.tid], x.coff, self.tids[x1.tid], x1.coff, 1 if cv['relu'] else 0,
                                                  self._blob(wc), f32(cv['bias'][0]), self._blob(wr), f32(rt['bias'][0]),
                                                  self.tids[ro.tid], ro.coff, 1 if rt['relu'] else 0,
-                                                 self.tids[po.tid] if po is not None else -1, po.coff if po is not None else 0),
+                                                 self.tids[po.tid] if po is not None else -1, po.coff if po is not None else 0,
+                                                 self.tids[s2d[0].tid] if s2d is not None else -1, s2d[1] if s2d is not None else 0),
                    'op_conv64_root')
 
     def _stem_fusion_pairs(self):
@@ -952,8 +1065,14 @@ class RealizedPlan(object):
         d.softmax_stat_slot = self._stat_slots.get(self._k, -1)
         d.out_nchw_f32 = op['out_nchw']
         d.out_H, d.out_W = op['out_hw']
+        d.s2d_tensor, d.s2d_coff = -1, 0
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
+        s2d = getattr(self, '_s2d_for', {}).get(self._k) if 'tap_dc' not in op else None
+        if s2d is not None:
+            # this conv's output feeds a neck up-fold: second copy in space-to-depth layout, 128-pixel kernel (the one whose epilogue has it)
+            d.s2d_tensor, d.s2d_coff = self.tids[s2d[0].tid], s2d[1]
+            variant = 0
         if variant is None:
             variant = (5 if conv64_eligible(op) else 7 if conv64s2_eligible(op) and self.plan.B * (op['Hm'] // 4) * (op['Wm'] // 32) >= 64
                        else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)

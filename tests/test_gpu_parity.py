@@ -335,6 +335,44 @@ def test_forward_stages_vs_oracle(dev, bb, shape):
         assert e <= bar, (name, e, bar)
 
 
+def test_neck_up_fold_vs_oracle(dev):
+    """RealizedPlan._neck_up_folds (round 4): the neck's composed proj3 + head2 1x1 folded INTO the transposed conv kfpn_up3 (the
+    1x1's share of the backbone feature as one more K-step per sub-pixel phase, read from a space-to-depth copy that the fused
+    level-2 tail writes): fused map z and logits against the oracle with the fold on and off - the fold must really have been
+    taken (one launch fewer, kernel names) and both forms meet the same bars."""
+    from rtm3d_amd import plan as plan_mod
+    bb, B, H, W = 'DLA-34', 2, 384, 1280
+    sd = weights.synth_state_dict(bb, 5, 'trained', heat_bias=-3.0)
+    x = weights.synth_images(B, H, W, seed=21)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _, lref, st = rtm3d_ref.model_forward(x, sd, bb, return_stages=True)
+    res = {}
+    v2_min = plan_mod.V2_MIN_TILES
+    for fold in (True, False):
+        plan_mod.FOLD_NECK_UP = fold
+        plan_mod.V2_MIN_TILES = 8          # (the fold needs the 256-pixel kernel; at B = 2 the two coarser levels have 15-60 tiles: take it anyway)
+        try:
+            m = make_model(bb, sd)
+            logits = m.forward_logits(x.to(dev))
+            plan = m._plan_for(B, H, W, dev)
+            names = plan.op_names
+            for lvl in (3, 4, 5):
+                assert any(n.startswith('kfpn_up%d+kfpn_proj%d' % (lvl, lvl)) for n in names) == fold, names
+            assert any('+s2d' in n for n in names) == fold, names
+            z = plan.download(plan.plan.named['z'])
+            errs = {'z': _rel_err(z, st['z'].numpy()), 'z_p999': float(np.percentile(np.abs(z - st['z'].numpy()), 99.9) / max(1.0, float(np.abs(st['z'].numpy()).max())))}
+            for name, a, b in zip(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset'], logits, lref):
+                errs[name] = _rel_err(a.cpu().numpy(), b.numpy())
+            res[fold] = (errs, len(names))
+            record_measurement('neck_up_fold_vs_oracle', 'fold_%s' % fold, errs)
+            for name, e in errs.items():
+                assert e <= (Z_PEAK_RTOL if name == 'z' else Z_P999_RTOL if name == 'z_p999' else LOGIT_RTOL), (fold, name, e)
+        finally:
+            plan_mod.FOLD_NECK_UP = True
+            plan_mod.V2_MIN_TILES = v2_min
+    assert res[True][1] == res[False][1] - 3
+
+
 def _check_device_decode(dev, m, lg, g, K, topk=100):
     """Reference logits in -> (1) the facade (Model.inference + optim_decode_bbox3d, detect.py:61-74) and (2) the
     fused device path (decode2d -> decode3d_slots, no host hop) against the reference's detections (bit-exact),
