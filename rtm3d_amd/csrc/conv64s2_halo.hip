@@ -13,10 +13,11 @@
 //     k-chunk is XORed with (column >> 1) & 7 (with the stride-1 key, column & 7, eight consecutive lanes would hit four slots
 //     twice); applied on the SOURCE side of the DMA, which copies linearly;
 //   * tickets, epilogue (bias + ReLU, v_permlane16_swap -> 16-byte stores) as conv64_halo.hip.
-// Measured (same box, bs=32, 1920 tiles): 0.051 ms against 0.071 on the generic kernel.  Timing-only variants: without the halo DMA
-// 0.043, without the MFMAs 0.043 - neither stream alone is what a tile (6.8 us for 2.1 us of MFMA time and 107 KB moved) waits
-// for; LDS operand reads (576 KB per tile), DMA, multiplies and stores each take 2-3 us and overlap only partly with eight
-// waves in lock step behind one barrier per tile.
+// Measured (same box, bs=32, 1920 tiles): 0.051-0.054 ms against 0.071-0.074 on the generic kernel.  Over the batch size the launch
+// time is 14.7 us + 4.9 us per tile and workgroup (conv64_halo.hip on its 256-pixel tiles: 15.3 us + 1.8 us): the per-tile cost is
+// 2.3x the 2.1 us of MFMA time.  What it is NOT (each tried on one box, no change): the halo DMA (timing-only build without it: -1 us
+// per tile), the MFMAs (without them: -1 us), LDS bank conflicts (48 % of the LDS cycles before the pixel-pair swap below, 0 after),
+// operand prefetch distance (one or two K-steps ahead), the place of the ticket draw relative to the stores.
 // K order: tap-major, 64 channels per tap as two 32-deep MFMAs (the generic kernel's order; fp32 accumulate).
 #include "common.h"
 
@@ -65,7 +66,12 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
     // stages piece (column tid >> 3, slot tid & 7) of the row's first 64 pixels - 512 consecutive pieces in LDS, one source
     // offset per row parity (the swizzle key ((hx >> 1) ^ (hy << 2)) & 7 depends on hy through its parity only) plus hy row
     // pitches added on the scalar side; the 65th column of row hy is staged by lanes 0-7 of wave hy & 7 (wave 0 also row 8).
-    const uint32_t hxl = (uint32_t)(tid >> 3), hcs = (uint32_t)(tid & 7);
+    // LDS POSITION pl of a row holds halo pixel hx = pl ^ ((pl >> 1) & 1) (pixels 2k, 2k+1 swapped for odd k): a wave reads
+    // same-parity pixels (2 frow + dx), which at a 128-byte pixel pitch would all sit in one half of the 256-byte bank row -
+    // 2-way conflicts on every ds_read_b128 (measured: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles); with the swap consecutive
+    // lanes alternate between the halves
+    const uint32_t pl = (uint32_t)(tid >> 3), hcs = (uint32_t)(tid & 7);
+    const uint32_t hxl = pl ^ ((pl >> 1) & 1);
     const uint32_t off_e = (hxl * (uint32_t)a.in_C + ((hcs ^ ((hxl >> 1) & 7)) * 8)) * 2;            // bytes
     const uint32_t off_o = (hxl * (uint32_t)a.in_C + ((hcs ^ (((hxl >> 1) ^ 4) & 7)) * 8)) * 2;
     // column 64 of row hy: ONE full 64-lane instruction on LDS pieces (hy * 65 + 64) * 8 .. + 63 = pixel (hy, 64) and, behind it,
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
     // no divergent branch around the asm, which cost SGPR -> scratch spills).  Row 8, the last: the lanes behind the halo re-read
     // pixel (8, 64) (the buffer ends in a 56-piece dead zone).
     const uint32_t cl = (uint32_t)(lane >> 3), sl = (uint32_t)(lane & 7);
-    const uint32_t nxc = cl - 1;                                                                       // column in row hy + 1 (lanes >= 8)
+    const uint32_t nxp = cl - 1, nxc = nxp ^ ((nxp >> 1) & 1);                                         // position / pixel in row hy + 1 (lanes >= 8)
     const uint32_t off_c_e = (cl == 0 ? 64u * (uint32_t)a.in_C + sl * 8                                // hy even: key of (hy, 64) = 0, of row hy + 1: odd
                                       : (uint32_t)(a.in_Wp * a.in_C) + nxc * (uint32_t)a.in_C + ((sl ^ (((nxc >> 1) ^ 4) & 7)) * 8)) * 2;
     const uint32_t off_c_o = (cl == 0 ? 64u * (uint32_t)a.in_C + ((sl ^ 4) * 8)                        // hy odd
@@ -120,6 +126,9 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
     // 16-byte slot of k-chunk (kk * 4 + fk): XOR key = ((hx >> 1) ^ (hy << 2)) & 7 with hx >> 1 = column + (dx == 2) (+ 16 for the
     // second fragment: no change mod 8), (hy << 2) & 7 = (dy & 1) << 2
     const uint32_t key0 = (uint32_t)(frow & 7), key1 = (uint32_t)((frow + 1) & 7);
+    // position of halo pixel hx = 2 * column + dx: hx ^ (((hx >> 1)) & 1) = hx + 1 (dx = 0), hx - 1 (dx = 1) when the column is odd,
+    // hx + 1 (dx = 2) when it is even (the 16-column offset of the second fragment does not change the parity)
+    const uint32_t adj = (uint32_t)(frow & 1) * 128;
     const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
     const f16x4 lo4 = {lo, lo, lo, lo};
 
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
         uint32_t fk2 = (uint32_t)fk;
         asm volatile("" : "+v"(fk2));               // (likewise: the store offset is recomputed per tile)
         const int so = (int)((fk2 & 1) * 16 + (fk2 >> 1) * 8);
+        u32x4 res16[2][2];                          // both rows' packed results: all four stores go out behind the ticket draw
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             f32x4 acc[2][2];
@@ -158,27 +168,28 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
             auto frag_addr = [&](int st, int q) -> uint32_t {
                 const int t = st >> 1, kk = st & 1, dy = t / 3, dx = t % 3;
                 const uint32_t key = (dx == 2 ? key1 : key0) ^ (uint32_t)((dy & 1) << 2);
-                return hb + (uint32_t)(((dy + 2 * ph) * S2_HALO_W + dx) * 128) + (uint32_t)(q * 32 * 128) + ((((uint32_t)(kk * 4 + fk)) ^ key) << 4);
+                const uint32_t swp = dx == 0 ? adj : (dx == 1 ? 0u - adj : 128u - adj);
+                return hb + (uint32_t)(((dy + 2 * ph) * S2_HALO_W + dx) * 128) + (uint32_t)(q * 32 * 128) + swp + ((((uint32_t)(kk * 4 + fk)) ^ key) << 4);
             };
-            f16x8 xc[2] = {S2_LDS_F16X8(frag_addr(0, 0)), S2_LDS_F16X8(frag_addr(0, 1))};
+            // (operands two steps ahead: one step of four MFMAs - 64 cycles - does not cover the LDS latency under load)
+            f16x8 x0[2] = {S2_LDS_F16X8(frag_addr(0, 0)), S2_LDS_F16X8(frag_addr(0, 1))};
+            f16x8 x1[2] = {S2_LDS_F16X8(frag_addr(1, 0)), S2_LDS_F16X8(frag_addr(1, 1))};
 #pragma unroll
             for (int st = 0; st < 18; ++st) {
-                f16x8 xn[2] = {xc[0], xc[1]};
-                if (st + 1 < 18) { xn[0] = S2_LDS_F16X8(frag_addr(st + 1, 0)); xn[1] = S2_LDS_F16X8(frag_addr(st + 1, 1)); }
+                f16x8 x2[2] = {x1[0], x1[1]};
+                if (st + 2 < 18) { x2[0] = S2_LDS_F16X8(frag_addr(st + 2, 0)); x2[1] = S2_LDS_F16X8(frag_addr(st + 2, 1)); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
-                        acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[st >> 1][st & 1][c], xc[q], acc[c][q], 0, 0, 0);
+                        acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[st >> 1][st & 1][c], x0[q], acc[c][q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                xc[0] = xn[0]; xc[1] = xn[1];
+                x0[0] = x1[0]; x0[1] = x1[1]; x1[0] = x2[0]; x1[1] = x2[1];
             }
-            // ---- epilogue of this row
+            // ---- this row's results: bias is in, ReLU, fp16, 8 consecutive channels per lane
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oy = ty * S2_TH + 2 * wh + ph, ox = tx * S2_TW + q * 16 + frow;
-                const size_t opix = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + wc * 32;
                 uint32_t u[2][2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -189,16 +200,25 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
                 }
                 const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
-                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                *(u32x4*)((f16*)a.out + opix + so) = o;
+                res16[ph][q] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
             }
         }
-        // one more ticket (for the tile after `nn`); slot it & 1 was read by everyone two barriers ago.  (Behind the stores: the
-        // compiler waits for the returning atomic with vmcnt(0), by then the next halo has long landed.)
+        // one more ticket (for the tile after `nn`); slot it & 1 was read by everyone two barriers ago.  IN FRONT of the stores: the
+        // compiler waits for the returning atomic with vmcnt(0), which here means this wave's halo DMA (long landed) - behind the
+        // stores it would be their acknowledgement, a memory round trip per tile with every other wave waiting at the barrier
+        // (that order cost 6.8 us per tile instead of ~3.5)
         if (!single && tid == 0) tk[it & 1] = (int)atomicAdd(ticket_ctr, 1u);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int oy = ty * S2_TH + 2 * wh + ph, ox = tx * S2_TW + q * 16 + frow;
+                const size_t opix = ((size_t)(n * a.out_Hp + oy + a.out_P) * a.out_Wp + ox + a.out_P) * a.out_C + g.out_coff + wc * 32;
+                *(u32x4*)((f16*)a.out + opix + so) = res16[ph][q];
+            }
         if (!more) break;
-        // the next tile's halo (issued before this tile's stores) must have landed; the last row's 2 stores may stay in flight
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // the next tile's halo (issued before this tile's stores) must have landed; the 4 stores may stay in flight
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         cur = nxt; nxt = nn;
         par ^= 1;
         ++it;
