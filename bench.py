@@ -716,7 +716,7 @@ def main():
         # HBM-side traffic of the dominant kernel: PMC counters cannot be collected live inside a timed
         # run, so the per-launch figure comes from the committed rocprofv3 --pmc profile of this workload
         traffic, traffic_src = None, None
-        for prof in ('r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
+        for prof in ('r04_pmc_heads.json', 'r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', prof)) as f:
                     pmc = json.load(f)

@@ -7,11 +7,11 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--steps 10 --warmup 3 --no-cpu-baseline --no-parity"
+B="--steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-sparse-probe"
 timeout -k 10 200 python3 $R/bench.py $B --per-op > $O/bench_n1.json 2> $O/bench_per_op.txt || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py $B > $O/trace.log 2>&1 || { tail -5 $O/trace.log; exit 1; }
 echo trace done
-P="--steps 5 --warmup 2 --no-cpu-baseline --no-parity --serial"
+P="--steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-sparse-probe --serial"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python3 $R/bench.py $P > $O/pmc_fetch.log 2>&1 || { tail -5 $O/pmc_fetch.log; exit 1; }
 echo pmc1 done
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_write -o pmc -- python3 $R/bench.py $P > $O/pmc_write.log 2>&1 || { tail -5 $O/pmc_write.log; exit 1; }
