@@ -34,7 +34,7 @@
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
 #define C64_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
-template <int RES>
+template <int RES, int S2D>
 __global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, unsigned int* ticket_ctr, const int single) {
     __shared__ __attribute__((aligned(128))) f16 lds[2 * C64_BUF_PIECES * 8];
     __shared__ int tk[3];
@@ -196,11 +196,21 @@ __global__ __launch_bounds__(512) void conv64_halo_kernel(const ConvKArgs a, uns
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
                 const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                 *(u32x4*)((f16*)a.out + opix[p] + so) = o;
+                if (S2D) {
+                    // second copy in space-to-depth layout (ConvKArgs.s2d: the neck's up-fold reads the feature from its transposed conv's
+                    // input grid): fragment p = tile row 2 wp + (p >> 1), column (p & 1) * 16 + frow -> phase (p >> 1, frow & 1)
+                    uint32_t l2 = (uint32_t)lane;
+                    asm volatile("" : "+v"(l2));        // (lane offset recomputed here: no register to carry it across the conv)
+                    const uint32_t fr2 = l2 & 15, f2 = l2 >> 4;
+                    const uint32_t loff = (fr2 >> 1) * (uint32_t)a.s_C + (fr2 & 1) * 64 + (f2 & 1) * 16 + (f2 >> 1) * 8;
+                    const f16* sb = a.s2d + ((size_t)(n * a.s_Hp + ty * 4 + wp + a.s_P) * a.s_Wp + tx * 16 + (p & 1) * 8 + a.s_P) * a.s_C + a.s_coff + (p >> 1) * 128 + wc * 32;
+                    *(u32x4*)((f16*)sb + loff) = o;
+                }
             }
         }
         if (!more) break;
-        // the next tile's halo (issued before this tile's loads and stores) must have landed; the 4 stores may stay in flight
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // the next tile's halo (issued before this tile's loads and stores) must have landed; the stores may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + 4 * S2D) : "memory");
         cur = nxt; nxt = nn;
         par ^= 1;
         ++it;
@@ -219,7 +229,10 @@ bool conv64_halo_supported(const ConvKArgs& a, int groups) {
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s) {
     const int total = (a.M / a.HmWm) * (a.Wm >> 5) * ((a.HmWm / a.Wm) >> 3);
     int grid = cu_count < total ? cu_count : total;
-    if (a.res) hipLaunchKernelGGL(conv64_halo_kernel<1>, dim3(grid), dim3(512), 0, s, a, ticket_ctr, total <= cu_count ? 1 : 0);
-    else hipLaunchKernelGGL(conv64_halo_kernel<0>, dim3(grid), dim3(512), 0, s, a, ticket_ctr, total <= cu_count ? 1 : 0);
+    const int single = total <= cu_count ? 1 : 0;
+    if (a.res && a.s2d) hipLaunchKernelGGL((conv64_halo_kernel<1, 1>), dim3(grid), dim3(512), 0, s, a, ticket_ctr, single);
+    else if (a.res) hipLaunchKernelGGL((conv64_halo_kernel<1, 0>), dim3(grid), dim3(512), 0, s, a, ticket_ctr, single);
+    else if (a.s2d) hipLaunchKernelGGL((conv64_halo_kernel<0, 1>), dim3(grid), dim3(512), 0, s, a, ticket_ctr, single);
+    else hipLaunchKernelGGL((conv64_halo_kernel<0, 0>), dim3(grid), dim3(512), 0, s, a, ticket_ctr, single);
     return hipGetLastError();
 }

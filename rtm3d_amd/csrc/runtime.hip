@@ -280,8 +280,8 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     if (d->s2d_tensor >= 0) {
         Tensor* s2 = get_tensor(ctx, d->s2d_tensor);
         if (!s2 || !out) RT_FAIL("op_conv: bad space-to-depth tensor %d", d->s2d_tensor);
-        if (d->kernel != 0 || d->groups != 1 || d->out_scale != 1 || d->out_oy[0] || d->out_ox[0] || (d->Hm & 1) || (d->Wm & 1) || (d->cout % 8))
-            RT_FAIL("op_conv: the space-to-depth copy needs kernel 0, one group, out_scale 1 and an even output height / width");
+        if ((d->kernel != 0 && d->kernel != 5) || d->groups != 1 || d->out_scale != 1 || d->out_oy[0] || d->out_ox[0] || (d->Hm & 1) || (d->Wm & 1) || (d->cout % 8))
+            RT_FAIL("op_conv: the space-to-depth copy needs kernel 0 or 5, one group, out_scale 1 and an even output height / width");
         if (s2->B != in->B || s2->H * 2 != d->Hm || s2->W * 2 != d->Wm || d->s2d_coff < 0 || d->s2d_coff + 4 * d->cout > s2->C || (d->s2d_coff % 8))
             RT_FAIL("op_conv: space-to-depth slice mismatch (half resolution, 4 x cout channels)");
         if (s2 == out || s2 == in || s2 == res) RT_FAIL("op_conv: the space-to-depth copy aliases an operand");

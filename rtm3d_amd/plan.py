@@ -734,8 +734,8 @@ class RealizedPlan(object):
                       and not any(k in ch for ch in tail.values()) and k not in tail]
                 if len(kt) == 1 and Cf == 64 and kt[0] < ku:
                     fold['tail'] = kt[0]
-                elif len(kf) == 1 and kf[0] < ku and not conv64_eligible(P.ops[kf[0]]) and not conv64s2_eligible(P.ops[kf[0]]):
-                    fold['feat'] = kf[0]
+                elif len(kf) == 1 and kf[0] < ku and not conv64s2_eligible(P.ops[kf[0]]):
+                    fold['feat'] = kf[0]            # (the 128-pixel kernel, or conv64_halo.hip for a 64 -> 64 3x3: both can emit the copy)
                 else:
                     ok = False
             # between the deconv's place and the 1x1's nothing may write h (the fused op runs at the 1x1's place)
@@ -1072,7 +1072,7 @@ class RealizedPlan(object):
         if s2d is not None:
             # this conv's output feeds a neck up-fold: second copy in space-to-depth layout, 128-pixel kernel (the one whose epilogue has it)
             d.s2d_tensor, d.s2d_coff = self.tids[s2d[0].tid], s2d[1]
-            variant = 0
+            variant = 5 if conv64_eligible(op) else 0
         if variant is None:
             variant = (5 if conv64_eligible(op) else 7 if conv64s2_eligible(op) and self.plan.B * (op['Hm'] // 4) * (op['Wm'] // 32) >= 64
                        else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)

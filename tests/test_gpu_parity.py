@@ -301,11 +301,12 @@ def test_sparse_heads_detections_vs_reference_golden(dev, fname):
 
 
 @pytest.mark.parametrize('bb,shape', [('DLA-34', (3, 96, 160)), ('RESNET-18', (3, 96, 160)), ('DLA-34', (2, 352, 1216)), ('RESNET-18', (1, 352, 1216)),
-                                      ('DLA-34', (1, 416, 1280))])
+                                      ('DLA-34', (1, 416, 1280)), ('RESNET-18', (8, 384, 1280))])
 def test_forward_stages_vs_oracle(dev, bb, shape):
     """Fresh seed: backbone features, fused map and logits against the oracle - batch 3 on a non-square small input; an ODD full-size
     shape (352 x 1216: maps of 88 x 304 ... 11 x 38, no level takes a halo-tile kernel except by accident of divisibility) and the
-    real-KITTI letterbox shape 416 x 1280."""
+    real-KITTI letterbox shape 416 x 1280; BASELINE config[1]'s shape (ResNet-18, bs=8, full size), where the neck
+    fold of level 4 is active with a residual 3x3 conv as the producer of the space-to-depth feature copy."""
     B, H, W = shape
     sd = weights.synth_state_dict(bb, 11, 'trained', heat_bias=-3.0)
     x = weights.synth_images(B, H, W, seed=77)
