@@ -688,6 +688,15 @@ class RealizedPlan(object):
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
 
+    @classmethod
+    def rewrites_only(cls, plan):
+        """An object that can find and build the realize-level rewrites of `plan` (project folds, level tails, neck up-folds)
+        WITHOUT a device context: for the CPU tests of their algebra and tap tables (tests/test_plan_cpu.py)."""
+        self = cls.__new__(cls)
+        self.plan, self.cache, self.ctx = plan, getattr(plan, 'cache', None), None
+        self._stat_slots = self._softmax_stat_producers()
+        return self
+
     def _neck_up_folds(self, tail):
         """Neck (models/nets/keypoint_fpn_fusion.py:35-46): x[i-1] = head(proj(cat[up(h), feat])) with up = ConvTranspose2d without
         bias or non-linearity and proj∘head already composed into ONE 1x1 conv A = [A_up | A_f]:

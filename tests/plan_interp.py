@@ -41,8 +41,11 @@ def run_plan(plan, x_nchw, half=False, prefill=None, yx=None):
                 wg = rnd(torch.from_numpy(op['w'][g]))                            # (taps, cout, cin)
                 for t, (dy, dx) in enumerate(op['taps'][g]):
                     assert -Pi <= dy and (Hm - 1) * s + dy < Hi + Pi and -Pi <= dx and (Wm - 1) * s + dx < Wi + Pi, op['name']
-                    xs = ibuf[:, Pi + dy: Pi + dy + (Hm - 1) * s + 1: s, Pi + dx: Pi + dx + (Wm - 1) * s + 1: s,
-                              inp.coff:inp.coff + inp.C]
+                    # (rtm3d_conv_desc.tap_dc: a tap may name another channel slice of the input tensor; cin channels each)
+                    c0 = inp.coff + (op['tap_dc'][g][t] if 'tap_dc' in op else 0)
+                    cw = op['cin'] if 'tap_dc' in op else inp.C
+                    assert c0 >= 0 and c0 + cw <= ibuf.shape[3], op['name']
+                    xs = ibuf[:, Pi + dy: Pi + dy + (Hm - 1) * s + 1: s, Pi + dx: Pi + dx + (Wm - 1) * s + 1: s, c0:c0 + cw]
                     acc += xs @ wg[t].T
                 acc = acc + torch.from_numpy(op['bias'][g])
                 oy, ox = op['out_off'][g]
@@ -58,6 +61,18 @@ def run_plan(plan, x_nchw, half=False, prefill=None, yx=None):
                     o = op['out'][g]
                     obuf, Po, Ho, Wo = view(o)
                     obuf[:, Po + oy: Po + oy + (Hm - 1) * sc + 1: sc, Po + ox: Po + ox + (Wm - 1) * sc + 1: sc, o.coff:o.coff + o.C] = rnd(acc)
+        elif op['op'] == 's2d_copy':
+            # the second, space-to-depth output of a feature's producer (RealizedPlan._neck_up_folds): pixel (y, x) of `src` ->
+            # pixel (y >> 1, x >> 1), channels coff + ((y & 1) * 2 + (x & 1)) * C + c of tensor `tid`
+            src = op['src']
+            sbuf, Ps, Hs, Ws = view(src)
+            dbuf = bufs[op['tid']]
+            Pd = plan.tensors[op['tid']]['pad']
+            v = sbuf[:, Ps:Ps + Hs, Ps:Ps + Ws, src.coff:src.coff + src.C]
+            for py in range(2):
+                for px in range(2):
+                    c0 = op['coff'] + (py * 2 + px) * src.C
+                    dbuf[:, Pd:Pd + Hs // 2, Pd:Pd + Ws // 2, c0:c0 + src.C] = v[:, py::2, px::2]
         elif op['op'] == 'headout':
             i = op['inp']
             ibuf, Pi, Hi, Wi = view(i)

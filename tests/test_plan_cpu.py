@@ -25,6 +25,64 @@ def test_plan_matches_oracle_fp32(bb):
         np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
+def test_realize_level_rewrites_keep_the_function(bb):
+    """Round 4: the rewrites RealizedPlan applies when it records a plan - a DLA block's `project` 1x1 as extra K-steps of the block's
+    second conv (rtm3d_conv_desc.tap_dc), the neck's proj+head 1x1 folded into the transposed conv in front of it with the feature read
+    from a space-to-depth copy - are exact in real arithmetic.  Checked WITHOUT a GPU: the rewritten op list (the same builders the
+    device path uses: _project_folds / _folded_conv / _neck_up_folds / _neck_fold_conv) through the CPU interpreter against the
+    original plan: fused map and logits to fp32 round-off; every fold really present."""
+    import copy
+    sd = weights.synth_state_dict(bb, 3, 'trained')
+    x = weights.synth_images(1, 64, 128, seed=5)
+    P = plan_mod.build_plan(sd, bb, 1, 64, 128)
+    outs0, fetch0 = run_plan(P, x)
+    v2_min = plan_mod.V2_MIN_TILES
+    plan_mod.V2_MIN_TILES = 1                   # (the neck fold is gated on a launch size the 64 x 128 test image does not reach)
+    try:
+        R = plan_mod.RealizedPlan.rewrites_only(P)
+        tail = R._level_tail_chains()
+        nfold = R._neck_up_folds(tail)
+        folds = R._project_folds()
+    finally:
+        plan_mod.V2_MIN_TILES = v2_min
+    if bb == 'DLA-34':
+        assert len(folds) == 3 and len(tail) == 1 and len(nfold) == 3, (folds, tail, nfold)
+    else:
+        assert len(folds) == 0 and len(nfold) >= 1, (folds, nfold)          # (ResNet's downsample 1x1s are stride 2: not foldable)
+    # rewritten plan: wider tensors for the space-to-depth copies, ops replaced
+    Q = copy.copy(P)
+    Q.tensors = [dict(t) for t in P.tensors]
+    for f in nfold:
+        Q.tensors[f['hs'].tid]['C'] += 4 * f['Cf']
+    skip = set(folds.values()) | {f['up'] for f in nfold}
+    neck_by = {f['pj']: f for f in nfold}
+    copy_after = {}
+    for f in nfold:
+        prod = tail[f['tail']][0] if 'tail' in f else f['feat']          # the op that writes the feature (the root of a fused tail, or a conv)
+        copy_after[prod] = {'op': 's2d_copy', 'src': P.ops[prod]['out'][0], 'tid': f['hs'].tid, 'coff': P.tensors[f['hs'].tid]['C']}
+    ops = []
+    for k, op in enumerate(P.ops):
+        if k in skip:
+            continue
+        if k in folds:
+            op = R._folded_conv(P.ops[k], P.ops[folds[k]])
+        if k in neck_by:
+            op = R._neck_fold_conv(neck_by[k])
+            assert len(op['taps'][0]) == 16 + neck_by[k]['Cf'] // 64 and op['cin'] == 64
+        ops.append(op)
+        if k in copy_after:
+            ops.append(copy_after[k])
+    Q.ops = ops
+    assert len(Q.ops) == len(P.ops) - len(folds)                          # project ops gone; each neck fold: -2 ops + 1 copy op
+    outs1, fetch1 = run_plan(Q, x)
+    np.testing.assert_allclose(fetch1(P.named['z']).numpy(), fetch0(P.named['z']).numpy(), atol=2e-5, rtol=1e-5)
+    for i in range(4):
+        np.testing.assert_allclose(fetch1(P.named['feat%d' % i]).numpy(), fetch0(P.named['feat%d' % i]).numpy(), atol=1e-5, rtol=1e-5)
+    for a, b in zip(outs1, outs0):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-5, rtol=1e-5)
+
+
 def test_plan_fp16_error_budget():
     """fp16 weights/activations with fp32 accumulation: logit error stays below 0.03 * logit scale."""
     bb = 'DLA-34'
