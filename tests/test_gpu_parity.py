@@ -1378,3 +1378,46 @@ def test_fp16_range_report_names_the_overflowing_tensor(dev):
     d = m2.inference([l.clone() for l in logits])                        # ... which the decode handles (no crash, no NaN-scored detection)
     if d[0][0] is not None:
         assert bool(torch.isfinite(d[1][0]).all())
+
+
+def test_detect_py_shaped_loop_on_the_kitti416_fixture(dev):
+    """the reference's detect.py loop (detect.py:56-74) with this package, on the real-KITTI letterbox
+    shape 1 x 3 x 416 x 1280 (reference-run fixture e2e_dla34_kitti416.npz): `Model.detect` gives the five lists, every reference
+    detection safely above the threshold is found with its vertices within VERT_TOL_PX, and `optim_decode_bbox3d` on those lists
+    returns a ParamList with the reference's fields whose kept set equals the set the fixture's raw solver states keep when the
+    detections match one to one."""
+    from rtm3d_amd import model_utils
+    g = load_golden('e2e_dla34_kitti416.npz')
+    bb = str(g['backbone'])
+    B, H, W = [int(v) for v in g['shape']]
+    assert (B, H, W) == (1, 416, 1280)
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
+    cfg = rtm3d_amd.kitti_config(bb)
+    model = rtm3d_amd.create_model(cfg).to(dev).eval()
+    model.load_state_dict(sd)
+    imgs = weights.synth_images(B, H, W, seed=int(g['img_seed']))
+    K = np.asarray(g['K'], np.float64)
+    preds = model.detect(imgs.to(dev))
+    clses, m_scores, m_projs, v_projs_regress, bboxes_2d = preds
+    assert clses[0] is not None
+    out = model_utils.optim_decode_bbox3d(clses[0].cpu().numpy(), v_projs_regress[0].cpu().numpy(), K, cfg.DETECTOR.dim_ref, [0, -0.5, 20])
+    for f in ('class', 'Ry', 'dimension', 'location', 'K'):
+        assert out.has_field(f)
+    assert np.asarray(out.get_field('dimension')).reshape(-1, 3).shape[1] == 3 and np.asarray(out.get_field('K')).reshape(-1, 9).shape[1] == 9
+    # detections against the reference's (margin rule of the golden tests)
+    rc, rs, rm, rv, _ = dets_from_golden(g, 'det_', 0)
+    tol = HM_RTOL * max(1.0, np.abs(g['logits_main_kf']).max())
+    sure = np.abs(np.log(rs.astype(np.float64) / (1.0 - rs.astype(np.float64))) - float(np.log(0.4 / 0.6))) > tol
+    got = {(int(c), int(mx // 4), int(my // 4)): v for c, (mx, my), v in
+           zip(clses[0].cpu().numpy(), m_projs[0].cpu().numpy(), v_projs_regress[0].cpu().numpy())}
+    checked = 0
+    for c, mp, v, ok in zip(rc, rm, rv, sure):
+        if ok:
+            key = (int(c), int(mp[0] // 4), int(mp[1] // 4))
+            assert key in got, key
+            assert np.abs(got[key] - v).max() < VERT_TOL_PX
+            checked += 1
+    assert checked >= 12
+    # the kept set: the reference keeps none of this synthetic-weight frame's detections (fun >= 0.1 for all), and so does the device
+    if len(rc) == len(clses[0]):
+        assert len(out.get_field('class')) == int((g['d3_raw_fun_0'] < 0.1).sum())
