@@ -537,3 +537,62 @@ def test_forward_on_two_streams_is_serialised():
             assert torch.equal(a, b)
         for a, b in zip(gb, rb):
             assert torch.equal(a, b)
+
+
+def test_round4_entry_points_refuse_bad_arguments():
+    """Error behaviour of what round 4 added to the C ABI: every refusal returns non-zero with a message and records nothing
+    (the plan stays usable)."""
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    _lib.check(lib.rtm3d_ctx_create(0, ctypes.byref(ctx)))
+    try:
+        def tensor(B, H, W, C, pad):
+            tid = ctypes.c_int()
+            _lib.check(lib.rtm3d_tensor_create(ctx, B, H, W, C, pad, ctypes.byref(tid)))
+            return tid.value
+
+        def blob(nbytes):
+            arr = np.zeros(nbytes, np.uint8)
+            bid = ctypes.c_int()
+            _lib.check(lib.rtm3d_blob_create(ctx, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, ctypes.byref(bid)))
+            return bid.value
+        t_in, t_cat, t_out, t_pool, t_s2d = tensor(1, 16, 64, 64, 1), tensor(1, 16, 64, 128, 1), tensor(1, 16, 64, 64, 1), tensor(1, 8, 32, 64, 1), tensor(1, 8, 32, 512, 1)
+        wc, bc, wr, br = blob(9 * 64 * 64 * 2), blob(64 * 4), blob(64 * 128 * 2), blob(64 * 4)
+        ok = lambda *a: lib.rtm3d_op_conv64_root(ctx, *a)
+        base = [t_in, 0, t_cat, 64, 1, wc, bc, wr, br, t_out, 0, 1, t_pool, 0, t_s2d, 256]
+        assert ok(*base) == 0
+        for idx, bad, what in ((2, t_out, b'overlaps'),          # x1 in the root's output tensor at the same channels
+                               (5, br, b'blob size'),            # wrong conv weight blob
+                               (12, t_in, b'pooled'),            # pooled output at full resolution
+                               (15, 320, b'space-to-depth'),     # 4 x 64 channels do not fit behind offset 320
+                               (14, t_out, b'space-to-depth')):  # copy at full resolution
+            args = list(base)
+            args[idx] = bad
+            if idx == 2:
+                args[3] = 0
+            assert ok(*args) != 0 and what in lib.rtm3d_last_error(), (idx, lib.rtm3d_last_error())
+        # conv descriptor: a tap naming channels outside the tensor; a space-to-depth copy on an odd map / with the wrong kernel
+        d = _lib.ConvDesc()
+        t_a, t_b = tensor(1, 8, 16, 128, 1), tensor(1, 8, 16, 128, 1)
+        d.in_tensor, d.out_tensor, d.res_tensor, d.s2d_tensor, d.softmax_stat_slot = t_a, t_b, -1, -1, -1
+        d.Hm, d.Wm, d.in_stride, d.out_scale, d.cin, d.cout, d.groups, d.ntaps = 8, 16, 1, 1, 64, 128, 1, 2
+        d.kernel, d.bn_tile = 0, 128
+        d.w_blob, d.bias_blob = blob(2 * 128 * 64 * 2), blob(128 * 4)
+        d.tap_dc[0][1] = 64
+        assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) == 0, lib.rtm3d_last_error()
+        d.tap_dc[0][1] = 96
+        assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) != 0 and b'outside' in lib.rtm3d_last_error()
+        d.tap_dc[0][1] = 64
+        t_half = tensor(1, 4, 8, 512, 0)
+        d.s2d_tensor, d.s2d_coff = t_half, 0
+        assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) == 0, lib.rtm3d_last_error()
+        d.s2d_coff = 8
+        assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) != 0 and b'space-to-depth' in lib.rtm3d_last_error()
+        d.s2d_coff, d.kernel = 0, 2
+        assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) != 0
+        # gather_peak_patches: capacity
+        z = torch.zeros(4, device='cuda')
+        rc = lib.rtm3d_gather_peak_patches(None, z.data_ptr(), 8, 8, 256, 1, 2, 100, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 150, 15, 1600)
+        assert rc != 0 and b'cannot hold' in lib.rtm3d_last_error()
+    finally:
+        lib.rtm3d_ctx_destroy(ctx)
