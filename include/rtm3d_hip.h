@@ -95,6 +95,8 @@ typedef struct rtm3d_conv_desc {
                                               s2d_coff + ((y & 1) * 2 + (x & 1)) * cout + c of the half-resolution s2d_tensor - so that the neck
                                               can read the feature map from the grid of its transposed conv's input (plan.py: _neck_up_folds).
                                               NOTE for callers that zero-initialise the struct: 0 is a valid tensor id, set -1 for "none". */
+    int in_s2d;                            /* kernel 7 only: in_tensor holds the SPACE-TO-DEPTH copy (half resolution, 4 x cin channels at in_coff) of the
+                                              map the conv is stated on (Hm, Wm, taps, stride as for the ordinary map) */
     int relu;
     int w_blob, bias_blob;                 /* packed fp16 weights (layout depends on `kernel`), fp32 bias [groups][cout_pad] */
     int kernel;                            /* 0 = MFMA implicit GEMM 128-px tile (cin % 64 == 0), 2 = MFMA 256x256 tile
@@ -140,7 +142,7 @@ int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv
  * with lane = fk * 16 + row, element j = root weight [tile * 16 + row][s * 32 + (j >> 2) * 16 + fk * 4 + (j & 3)] over the
  * concatenated input [x2 | x1] (the K order in which the conv's accumulator fragments are handed to the root's MFMAs);
  * fp32 biases [64] with BN folded.  Same result as the rtm3d_op_conv / rtm3d_op_maxpool launches it replaces up to fp32
- * summation order.  s2d_tensor >= 0: `out` is written a second time in space-to-depth layout - pixel (y, x) to half-resolution
+ * summation order.  out_tensor < 0: the ordinary copy of `out` is not written (needs s2d_tensor).  s2d_tensor >= 0: `out` is written a second time in space-to-depth layout - pixel (y, x) to half-resolution
  * pixel (y >> 1, x >> 1), channels s2d_coff + ((y & 1) * 2 + (x & 1)) * 64 + c of s2d_tensor - which lets the neck read the
  * feature map at the resolution of the transposed conv's INPUT grid (rtm3d_amd/plan.py: RealizedPlan._neck_up_folds).        */
 int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,

@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
         ('out_oy', c_int * MAX_GROUPS), ('out_ox', c_int * MAX_GROUPS),
         ('tap_dy', (c_int * MAX_TAPS) * MAX_GROUPS), ('tap_dx', (c_int * MAX_TAPS) * MAX_GROUPS),
         ('tap_dc', (c_int * MAX_TAPS) * MAX_GROUPS),
-        ('s2d_tensor', c_int), ('s2d_coff', c_int),
+        ('s2d_tensor', c_int), ('s2d_coff', c_int), ('in_s2d', c_int),
         ('relu', c_int),
         ('w_blob', c_int), ('bias_blob', c_int),
         ('kernel', c_int), ('bn_tile', c_int),

@@ -58,6 +58,7 @@ struct ConvKArgs {
     // pixel (y >> 1, x >> 1), channels s_coff + ((y & 1) * 2 + (x & 1)) * cout + c
     f16* s2d;
     int s_Hp, s_Wp, s_C, s_P, s_coff;
+    int in_s2d;                   // conv64s2_halo.hip: `in` is the space-to-depth copy (half resolution, 4 x 64 channels at in_coff) of the 64-channel input map
     ConvGroupArgs g[RT_MAX_GROUPS];
 };
 

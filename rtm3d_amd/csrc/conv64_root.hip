@@ -46,7 +46,8 @@ __device__ __forceinline__ uint32_t cr_pkmax(uint32_t x, uint32_t y) {
     return r;
 }
 
-template <int POOL, int S2D>
+// NORM = 0: the ordinary copy of `out` is not written (r.out null): every reader takes the space-to-depth copy (S2D = 1)
+template <int POOL, int S2D, int NORM>
 __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, const RootKArgs r, unsigned int* ticket_ctr, const int single) {
     __shared__ __attribute__((aligned(128))) f16 lds[(2 * C64_BUF_PIECES + CR_W_PIECES + CR_X_PIECES) * 8];
     __shared__ __attribute__((aligned(16))) float sbias[128];      // [0, 64): conv bias, [64, 128): root bias
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
                 o[q][0] = s0[0]; o[q][1] = s1[0]; o[q][2] = s0[1]; o[q][3] = s1[1];
                 const u32x4 ov = {o[q][0], o[q][1], o[q][2], o[q][3]};
-                *(u32x4*)(obase + (size_t)(q * r.o_Wp * r.o_C + cp * 32) + olane) = ov;
+                if (NORM) *(u32x4*)(obase + (size_t)(q * r.o_Wp * r.o_C + cp * 32) + olane) = ov;
                 if (S2D) {
                     // space-to-depth copy: this lane's pixel (row 2 wp + q, column wc * 16 + frow of the tile) has phase (q, frow & 1);
                     // wave-uniform base + a 32-bit lane offset recomputed here (the kernel has no register to keep it in)
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(512) void conv64_root_kernel(const ConvKArgs a, con
         }
         if (!more) break;
         // the next tile's halo (issued before this tile's loads and stores) must have landed; the stores may stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 + POOL + 4 * S2D) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * NORM + POOL + 4 * S2D) : "memory");
         cur = nxt; nxt = nn;
         par ^= 1;
         ++it;
@@ -322,9 +323,12 @@ hipError_t launch_conv64_root(const ConvKArgs& a, const RootKArgs& r, int cu_cou
     const int total = (a.M / a.HmWm) * (a.Wm >> 5) * ((a.HmWm / a.Wm) >> 3);
     const int grid = cu_count < total ? cu_count : total;
     const int single = total <= cu_count ? 1 : 0;
-    if (r.pool && r.s2d) hipLaunchKernelGGL((conv64_root_kernel<1, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
-    else if (r.pool) hipLaunchKernelGGL((conv64_root_kernel<1, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
-    else if (r.s2d) hipLaunchKernelGGL((conv64_root_kernel<0, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
-    else hipLaunchKernelGGL((conv64_root_kernel<0, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    if (!r.out && !r.s2d) return hipErrorInvalidValue;
+    if (r.pool && r.s2d && !r.out) hipLaunchKernelGGL((conv64_root_kernel<1, 1, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.s2d && !r.out) hipLaunchKernelGGL((conv64_root_kernel<0, 1, 0>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.pool && r.s2d) hipLaunchKernelGGL((conv64_root_kernel<1, 1, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.pool) hipLaunchKernelGGL((conv64_root_kernel<1, 0, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else if (r.s2d) hipLaunchKernelGGL((conv64_root_kernel<0, 1, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
+    else hipLaunchKernelGGL((conv64_root_kernel<0, 0, 1>), dim3(grid), dim3(512), 0, s, a, r, ticket_ctr, single);
     return hipGetLastError();
 }

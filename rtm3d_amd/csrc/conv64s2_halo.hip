@@ -70,21 +70,32 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
     // same-parity pixels (2 frow + dx), which at a 128-byte pixel pitch would all sit in one half of the 256-byte bank row -
     // 2-way conflicts on every ds_read_b128 (measured: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles); with the swap consecutive
     // lanes alternate between the halves
+    // Two input layouts: the ordinary padded NHWC map at full resolution, or (a.in_s2d) its SPACE-TO-DEPTH copy - full-resolution
+    // pixel (y, x) at half-resolution pixel (y >> 1, x >> 1), channel slice ((y & 1) * 2 + (x & 1)) * 64 of a.in - which is what the
+    // neck reads (plan.py: _neck_up_folds); reading it here too lets the producer skip the ordinary copy.  Halo column hx / row hy
+    // = full-resolution column 2 ox0 - 1 + hx / row 2 oy0 - 1 + hy; element offsets relative to the tile's base pixel
+    // (ordinary: (2 oy0 - 1, 2 ox0 - 1); s2d: half-resolution pixel (oy0 - 1, ox0 - 1)):
+    const bool s2 = a.in_s2d != 0;
+    const uint32_t inC = (uint32_t)a.in_C, rp = (uint32_t)(a.in_Wp * a.in_C);
+    auto pxo = [&](uint32_t hx) -> uint32_t { return s2 ? ((hx + 1) >> 1) * inC + ((hx + 1) & 1) * 64 : hx * inC; };
     const uint32_t pl = (uint32_t)(tid >> 3), hcs = (uint32_t)(tid & 7);
     const uint32_t hxl = pl ^ ((pl >> 1) & 1);
-    const uint32_t off_e = (hxl * (uint32_t)a.in_C + ((hcs ^ ((hxl >> 1) & 7)) * 8)) * 2;            // bytes
-    const uint32_t off_o = (hxl * (uint32_t)a.in_C + ((hcs ^ (((hxl >> 1) ^ 4) & 7)) * 8)) * 2;
+    const uint32_t off_e = (pxo(hxl) + ((hcs ^ ((hxl >> 1) & 7)) * 8)) * 2;            // bytes
+    const uint32_t off_o = (pxo(hxl) + ((hcs ^ (((hxl >> 1) ^ 4) & 7)) * 8)) * 2;
     // column 64 of row hy: ONE full 64-lane instruction on LDS pieces (hy * 65 + 64) * 8 .. + 63 = pixel (hy, 64) and, behind it,
     // pixels 0 .. 6 of row hy + 1 - lanes 8 .. 63 stage exactly what belongs there (the row instruction writes the same bytes:
     // no divergent branch around the asm, which cost SGPR -> scratch spills).  Row 8, the last: the lanes behind the halo re-read
     // pixel (8, 64) (the buffer ends in a 56-piece dead zone).
     const uint32_t cl = (uint32_t)(lane >> 3), sl = (uint32_t)(lane & 7);
     const uint32_t nxp = cl - 1, nxc = nxp ^ ((nxp >> 1) & 1);                                         // position / pixel in row hy + 1 (lanes >= 8)
-    const uint32_t off_c_e = (cl == 0 ? 64u * (uint32_t)a.in_C + sl * 8                                // hy even: key of (hy, 64) = 0, of row hy + 1: odd
-                                      : (uint32_t)(a.in_Wp * a.in_C) + nxc * (uint32_t)a.in_C + ((sl ^ (((nxc >> 1) ^ 4) & 7)) * 8)) * 2;
-    const uint32_t off_c_o = (cl == 0 ? 64u * (uint32_t)a.in_C + ((sl ^ 4) * 8)                        // hy odd
-                                      : (uint32_t)(a.in_Wp * a.in_C) + nxc * (uint32_t)a.in_C + ((sl ^ ((nxc >> 1) & 7)) * 8)) * 2;
-    // (hy = 8, even, every lane: (64 * in_C + slot * 8) * 2, recomputed at its one use per tile: the kernel has no register to spare)
+    // offset of row hy + 1 relative to row hy: one row pitch (ordinary); s2d: rows alternate between the two row phases of one
+    // half-resolution row (hy odd -> even: + 128 channels) and step to the next half-resolution row (hy even -> odd: + pitch - 128)
+    const uint32_t drow_e = s2 ? rp - 128 : rp, drow_o = s2 ? 128u : rp;
+    const uint32_t off_c_e = (cl == 0 ? pxo(64) + sl * 8                                               // hy even: key of (hy, 64) = 0, of row hy + 1: odd
+                                      : drow_e + pxo(nxc) + ((sl ^ (((nxc >> 1) ^ 4) & 7)) * 8)) * 2;
+    const uint32_t off_c_o = (cl == 0 ? pxo(64) + ((sl ^ 4) * 8)                                       // hy odd
+                                      : drow_o + pxo(nxc) + ((sl ^ ((nxc >> 1) & 7)) * 8)) * 2;
+    // (hy = 8, even, every lane: (pxo(64) + slot * 8) * 2, recomputed at its one use per tile: the kernel has no register to spare)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
 
     // tickets: as conv64_halo.hip
@@ -100,24 +111,26 @@ __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, u
     if (cur >= total) return;
     __syncthreads();                                // tk[0..1] are reused as the per-tile slots below
 
-    auto halo_origin = [&](int v) -> size_t {       // input pixel (2 * oy0 - 1, 2 * ox0 - 1) of tile v
+    auto halo_origin = [&](int v) -> size_t {       // the tile's base pixel (see above)
         const int n = v / tpi, r = v - n * tpi;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        if (s2) return ((size_t)(n * a.in_Hp + ty * S2_TH - 1 + a.in_P) * a.in_Wp + tx * S2_TW - 1 + a.in_P) * a.in_C + g.in_coff;
         return ((size_t)(n * a.in_Hp + 2 * ty * S2_TH - 1 + a.in_P) * a.in_Wp + 2 * tx * S2_TW - 1 + a.in_P) * a.in_C + g.in_coff;
     };
-    const size_t row_pitch = (size_t)a.in_Wp * a.in_C;
+    // element offset of halo row hy relative to the base pixel
+    auto rowo = [&](int hy) -> size_t { return s2 ? (size_t)((hy + 1) >> 1) * rp + (size_t)(((hy + 1) & 1) * 128) : (size_t)hy * rp; };
     auto stage = [&](int v, int par) {
         const f16* src = a.in + halo_origin(v);
         const uint32_t lb = lds_base + (uint32_t)(par * S2_BUF_PIECES * 16);
 #pragma unroll
         for (int hy = 0; hy < S2_HALO_H; ++hy)          // columns 0 .. 63 of row hy: LDS pieces (hy * 65) * 8 + tid
-            S2_DMA16((hy & 1) ? off_o : off_e, src + hy * row_pitch, __builtin_amdgcn_readfirstlane(lb + (uint32_t)((hy * S2_HALO_W * 8 + wave * 64) * 16)));
+            S2_DMA16((hy & 1) ? off_o : off_e, src + rowo(hy), __builtin_amdgcn_readfirstlane(lb + (uint32_t)((hy * S2_HALO_W * 8 + wave * 64) * 16)));
         // column 64 of row `wave` (wave 0: also row 8)
-        S2_DMA16((wave & 1) ? off_c_o : off_c_e, src + wave * row_pitch, __builtin_amdgcn_readfirstlane(lb + (uint32_t)(((wave * S2_HALO_W + 64) * 8) * 16)));
+        S2_DMA16((wave & 1) ? off_c_o : off_c_e, src + rowo(wave), __builtin_amdgcn_readfirstlane(lb + (uint32_t)(((wave * S2_HALO_W + 64) * 8) * 16)));
         if (wave == 0) {
             uint32_t l2 = (uint32_t)lane;
             asm volatile("" : "+v"(l2));            // not loop-invariant as far as the compiler can tell
-            S2_DMA16((64u * (uint32_t)a.in_C + (l2 & 7) * 8) * 2, src + 8 * row_pitch, __builtin_amdgcn_readfirstlane(lb + (uint32_t)(((8 * S2_HALO_W + 64) * 8) * 16)));
+            S2_DMA16((pxo(64) + (l2 & 7) * 8) * 2, src + rowo(8), __builtin_amdgcn_readfirstlane(lb + (uint32_t)(((8 * S2_HALO_W + 64) * 8) * 16)));
         }
     };
 

@@ -250,7 +250,10 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         for (int t = 0; t < d->ntaps; ++t) {
             const int dy = d->tap_dy[g][t], dx = d->tap_dx[g][t];
             const int ylo = dy, yhi = (d->Hm - 1) * d->in_stride + dy, xlo = dx, xhi = (d->Wm - 1) * d->in_stride + dx;
-            if (ylo < -in->P || xlo < -in->P || yhi >= in->H + in->P || xhi >= in->W + in->P)
+            // (in_s2d: in_tensor is the half-resolution space-to-depth copy of the map the taps are stated on; its one-pixel border
+            // stands for a two-pixel border of that map)
+            const int Hin = d->in_s2d ? 2 * in->H : in->H, Win = d->in_s2d ? 2 * in->W : in->W, Pin = d->in_s2d ? (in->P >= 1 ? 2 : 0) : in->P;
+            if (ylo < -Pin || xlo < -Pin || yhi >= Hin + Pin || xhi >= Win + Pin)
                 RT_FAIL("op_conv: tap (%d,%d) leaves the padded input (H=%d W=%d pad=%d, Hm=%d Wm=%d stride=%d)", dy, dx, in->H, in->W, in->P, d->Hm, d->Wm, d->in_stride);
             const int dc = d->tap_dc[g][t];
             if (dc && d->kernel != 0 && d->kernel != 2) RT_FAIL("op_conv: per-tap channel offsets need kernel 0 or 2");
@@ -287,6 +290,10 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         if (s2 == out || s2 == in || s2 == res) RT_FAIL("op_conv: the space-to-depth copy aliases an operand");
         a.s2d = s2->base; a.s_Hp = s2->Hp; a.s_Wp = s2->Wp; a.s_C = s2->C; a.s_P = s2->P; a.s_coff = d->s2d_coff;
     }
+    if (d->in_s2d) {
+        if (d->kernel != 7 || d->groups != 1) RT_FAIL("op_conv: a space-to-depth INPUT is read by kernel 7 only");
+        if (d->in_coff[0] + 4 * d->cin > in->C || in->P < 1) RT_FAIL("op_conv: the space-to-depth input needs 4 x cin channels behind in_coff and a border >= 1");
+    }
     op.groups = d->groups; op.epi_nchw = d->out_nchw_f32 ? 1 : 0; op.out_slot = d->out_nchw_f32 - 1;
     int stat_slot = -1;
     const double M = (double)a.M;
@@ -320,6 +327,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         // 64 -> 128 channel 3x3 STRIDE-2 halo kernel with the filter bank in registers (conv64s2_halo.hip)
         if (d->out_nchw_f32 || res) RT_FAIL("op_conv(conv64s2): NCHW output / residual unsupported");
         a.cpt = 1; a.ksteps = 9; a.MT = 0; a.NT = 1;
+        a.in_s2d = d->in_s2d ? 1 : 0;
         if (!conv64s2_halo_supported(a, d->groups)) RT_FAIL("op_conv(conv64s2): needs one 64->128 3x3 stride-2 conv onto a map with W %% 32 == 0, H %% 4 == 0 (input border >= 1)");
         if (wbytes != (size_t)9 * 64 * 128 * sizeof(f16) || bbytes != 128 * sizeof(float)) RT_FAIL("op_conv(conv64s2): weight/bias blob size mismatch");
         if (ctx->ticket_slots_used >= TICKET_SLOTS) RT_FAIL("op_conv(conv64s2): out of ticket counters");
@@ -519,10 +527,11 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
                                     int s2d_tensor, int s2d_coff) {
     Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
     Tensor* res = ctx ? get_tensor(ctx, res_tensor) : nullptr;
-    Tensor* out = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    Tensor* out = ctx && out_tensor >= 0 ? get_tensor(ctx, out_tensor) : nullptr;
     Tensor* pool = ctx && pool_tensor >= 0 ? get_tensor(ctx, pool_tensor) : nullptr;
     Tensor* s2d = ctx && s2d_tensor >= 0 ? get_tensor(ctx, s2d_tensor) : nullptr;
-    if (!in || !res || !out || (pool_tensor >= 0 && !pool) || (s2d_tensor >= 0 && !s2d)) RT_FAIL("op_conv64_root: bad tensors");
+    if (!in || !res || (out_tensor >= 0 && !out) || (pool_tensor >= 0 && !pool) || (s2d_tensor >= 0 && !s2d)) RT_FAIL("op_conv64_root: bad tensors");
+    if (!out && !s2d) RT_FAIL("op_conv64_root: out_tensor < 0 (no ordinary copy of the root output) needs a space-to-depth copy");
     if (s2d) {
         if (s2d->H * 2 != in->H || s2d->W * 2 != in->W || s2d->B != in->B || s2d_coff < 0 || s2d_coff + 256 > s2d->C || (s2d_coff % 8))
             RT_FAIL("op_conv64_root: space-to-depth output slice mismatch (half resolution, 4 x 64 channels)");
@@ -531,10 +540,10 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
     if (in->P < 1 || in_coff < 0 || in_coff + 64 > in->C || (in_coff % 8)) RT_FAIL("op_conv64_root: input slice mismatch (64 channels, border >= 1)");
     if (in->H % 8 || in->W % 32) RT_FAIL("op_conv64_root: needs H %% 8 == 0 and W %% 32 == 0 (got %dx%d)", in->H, in->W);
     for (Tensor* t : {res, out})
-        if (t->H != in->H || t->W != in->W || t->B != in->B) RT_FAIL("op_conv64_root: residual / output shape mismatch");
-    if (res_coff < 0 || res_coff + 64 > res->C || (res_coff % 8) || out_coff < 0 || out_coff + 64 > out->C || (out_coff % 8)) RT_FAIL("op_conv64_root: residual / output slice mismatch");
-    if (res == out && res_coff < out_coff + 64 && out_coff < res_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps x1 (another workgroup may still read it)");
-    if (in == out && in_coff < out_coff + 64 && out_coff < in_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps the conv input");
+        if (t && (t->H != in->H || t->W != in->W || t->B != in->B)) RT_FAIL("op_conv64_root: residual / output shape mismatch");
+    if (res_coff < 0 || res_coff + 64 > res->C || (res_coff % 8) || (out && (out_coff < 0 || out_coff + 64 > out->C || (out_coff % 8)))) RT_FAIL("op_conv64_root: residual / output slice mismatch");
+    if (out && res == out && res_coff < out_coff + 64 && out_coff < res_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps x1 (another workgroup may still read it)");
+    if (out && in == out && in_coff < out_coff + 64 && out_coff < in_coff + 64) RT_FAIL("op_conv64_root: the root output overlaps the conv input");
     if (pool) {
         if (pool->H * 2 != in->H || pool->W * 2 != in->W || pool->B != in->B || pool_coff < 0 || pool_coff + 64 > pool->C || (pool_coff % 8))
             RT_FAIL("op_conv64_root: pooled output slice mismatch (half resolution, 64 channels)");
@@ -560,7 +569,8 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
     a.g[0].in_coff = in_coff; a.g[0].res_coff = res_coff;
     RootKArgs& r = op.root;
     memset(&r, 0, sizeof(r));
-    r.w = w1; r.bias = b1; r.out = out->base; r.o_Hp = out->Hp; r.o_Wp = out->Wp; r.o_C = out->C; r.o_P = out->P; r.o_coff = out_coff;
+    r.w = w1; r.bias = b1;
+    if (out) { r.out = out->base; r.o_Hp = out->Hp; r.o_Wp = out->Wp; r.o_C = out->C; r.o_P = out->P; r.o_coff = out_coff; }
     r.relu = root_relu ? 1 : 0;
     if (pool) { r.pool = pool->base; r.p_Hp = pool->Hp; r.p_Wp = pool->Wp; r.p_C = pool->C; r.p_P = pool->P; r.p_coff = pool_coff; }
     if (s2d) { r.s2d = s2d->base; r.s_Hp = s2d->Hp; r.s_Wp = s2d->Wp; r.s_C = s2d->C; r.s_P = s2d->P; r.s_coff = s2d_coff; }
@@ -569,7 +579,7 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
     if (s2d) op.name += "+s2d";
     const double M = (double)a.M;
     op.flops = 2.0 * M * (9.0 * 64 * 64 + 128.0 * 64);
-    op.bytes = 2.0 * M * (64.0 * 3 + (pool ? 16.0 : 0.0) + (s2d ? 64.0 : 0.0));      // conv input, x1, root output (+ the pooled map, + the second copy)
+    op.bytes = 2.0 * M * (64.0 * 2 + (out ? 64.0 : 0.0) + (pool ? 16.0 : 0.0) + (s2d ? 64.0 : 0.0));      // conv input, x1, root output (+ the pooled map, + the second copy)
     ctx->ops.push_back(op);
     return 0;
 }

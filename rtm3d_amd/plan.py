@@ -596,6 +596,14 @@ def pack_conv64_weights(wt):
     return np.ascontiguousarray(w).astype(np.float16).reshape(-1)
 
 
+S2D_ONLY = os.environ.get('RTM3D_S2D_ONLY', '1') != '0'   # a fused level tail skips the ordinary copy of its output when every reader can take the space-to-depth one
+
+
+def folds_pre(rp):
+    """(indices of convs that the project fold rewrites: they keep their ordinary input)"""
+    return set(rp._project_folds().keys()) if FOLD_PROJECT else set()
+
+
 def A_bias(J, D):
     """A_up applied to the transposed conv's own bias (zero for the reference's UpSample, models/nets/module.py:9: bias=False)."""
     A_up = J['w'][0][0][:, :256].astype(np.float64)
@@ -643,6 +651,21 @@ class RealizedPlan(object):
         nfold = self._neck_up_folds(tail) if FOLD_NECK_UP else []
         widen = {f['hs'].tid: 4 * f['Cf'] for f in nfold}    # device tensors that also hold a space-to-depth copy of a backbone feature
         self._s2d_for = {f['feat']: (f['hs'], plan.tensors[f['hs'].tid]['C']) for f in nfold if 'feat' in f}
+        # a level tail whose ordinary output has, besides the folded 1x1 and its own pool, ONE reader that can take the space-to-depth
+        # copy instead (the next level's stride-2 entry on conv64s2_halo.hip) does not write the ordinary copy at all
+        self._in_s2d_for, self._s2d_only = {}, {}
+        for f in nfold:
+            if 'tail' not in f or not S2D_ONLY:
+                continue
+            ro = plan.ops[tail[f['tail']][0]]['out'][0]
+            own = set([f['tail'], f['up'], f['pj']] + list(tail[f['tail']]))
+            readers = [j for j, o in enumerate(plan.ops) if j not in own and self._reads(o, ro.tid) and self._reads_slice(o, ro)]
+            if (len(readers) == 1 and conv64s2_eligible(plan.ops[readers[0]]) and plan.ops[readers[0]].get('variant') is None
+                    and plan.B * (plan.ops[readers[0]]['Hm'] // 4) * (plan.ops[readers[0]]['Wm'] // 32) >= 64
+                    and plan.ops[readers[0]]['inp'][0].coff == ro.coff and readers[0] not in folds_pre(self)):
+                f['s2d_only'] = True
+                self._in_s2d_for[readers[0]] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
+                self._s2d_only[(ro.tid, ro.coff, ro.C)] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
         for i, t in enumerate(plan.tensors):
             tid = ctypes.c_int()
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'] + widen.get(i, 0), t['pad'], ctypes.byref(tid)), 'tensor_create')
@@ -677,7 +700,8 @@ class RealizedPlan(object):
                 root = plan.ops[tail[k][0]]
                 pool = plan.ops[tail[k][1]] if len(tail[k]) > 1 else None
                 f = s2d_of.get(k)
-                self._op_conv64_root(op, root, pool, s2d=(f['hs'], plan.tensors[f['hs'].tid]['C']) if f else None)
+                self._op_conv64_root(op, root, pool, s2d=(f['hs'], plan.tensors[f['hs'].tid]['C']) if f else None,
+                                     skip_out=bool(f and f.get('s2d_only')))
                 self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else '') + ('+s2d' if f else ''))
                 skip.update(tail[k])
                 continue
@@ -890,7 +914,7 @@ class RealizedPlan(object):
             return hit(op['z_in'], op['z_in'].C) or any(hit(u, u.C) for u in op['us'])
         return False
 
-    def _op_conv64_root(self, cv, rt, pool, s2d=None):
+    def _op_conv64_root(self, cv, rt, pool, s2d=None, skip_out=False):
         f32 = lambda v: self._blob(np.ascontiguousarray(v, np.float32))
         x, x1, ro = cv['inp'][0], cv['res'][0], rt['out'][0]
         po = pool['out'] if pool is not None else None
@@ -898,7 +922,7 @@ class RealizedPlan(object):
         wr = self._packed(rt, 0, 'root64', 0, lambda: pack_root64_weights(rt['w'][0][0]))
         _lib.check(self.lib.rtm3d_op_conv64_root(self.ctx, self.tids[x.tid], x.coff, self.tids[x1.tid], x1.coff, 1 if cv['relu'] else 0,
                                                  self._blob(wc), f32(cv['bias'][0]), self._blob(wr), f32(rt['bias'][0]),
-                                                 self.tids[ro.tid], ro.coff, 1 if rt['relu'] else 0,
+                                                 -1 if skip_out else self.tids[ro.tid], ro.coff, 1 if rt['relu'] else 0,
                                                  self.tids[po.tid] if po is not None else -1, po.coff if po is not None else 0,
                                                  self.tids[s2d[0].tid] if s2d is not None else -1, s2d[1] if s2d is not None else 0),
                    'op_conv64_root')
@@ -1074,7 +1098,7 @@ class RealizedPlan(object):
         d.softmax_stat_slot = self._stat_slots.get(self._k, -1)
         d.out_nchw_f32 = op['out_nchw']
         d.out_H, d.out_W = op['out_hw']
-        d.s2d_tensor, d.s2d_coff = -1, 0
+        d.s2d_tensor, d.s2d_coff, d.in_s2d = -1, 0, 0
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
         s2d = getattr(self, '_s2d_for', {}).get(self._k) if 'tap_dc' not in op else None
@@ -1089,6 +1113,9 @@ class RealizedPlan(object):
         if variant == 7:
             assert conv64s2_eligible(op), op['name']
             d.kernel, d.bn_tile = 7, 128
+            src = getattr(self, '_in_s2d_for', {}).get(self._k)
+            if src is not None:                   # the producer wrote only the space-to-depth copy of this conv's input
+                d.in_tensor, d.in_coff[0], d.in_s2d = self.tids[src[0].tid], src[1], 1
             d.w_blob = self._blob(self._packed(op, 0, 'c64s2', 0, lambda: pack_conv64s2_weights(op['w'][0])))
             d.bias_blob = self._blob(np.ascontiguousarray(op['bias'][0], np.float32))
         elif variant == 6:
@@ -1222,6 +1249,17 @@ class RealizedPlan(object):
     def download(self, s):
         """Debug: fp32 NCHW copy of a Slice."""
         t = self.plan.tensors[s.tid]
+        src = getattr(self, '_s2d_only', {}).get((s.tid, s.coff, s.C))
+        if src is not None:
+            # only the space-to-depth copy of this map exists on the device: gather its four phase slices back
+            out = np.empty((self.plan.B, s.C, t['H'], t['W']), np.float32)
+            ph = np.empty((self.plan.B, s.C, t['H'] // 2, t['W'] // 2), np.float32)
+            for py in range(2):
+                for px in range(2):
+                    _lib.check(self.lib.rtm3d_tensor_download(self.ctx, self.tids[src[0].tid], src[1] + (py * 2 + px) * s.C, s.C,
+                                                              ph.ctypes.data_as(ctypes.c_void_p)), 'tensor_download')
+                    out[:, :, py::2, px::2] = ph
+            return out
         out = np.empty((self.plan.B, s.C, t['H'], t['W']), np.float32)
         _lib.check(self.lib.rtm3d_tensor_download(self.ctx, self.tids[s.tid], s.coff, s.C, out.ctypes.data_as(ctypes.c_void_p)), 'tensor_download')
         return out
