@@ -94,6 +94,8 @@ typedef struct rtm3d_conv_desc {
                                               written a SECOND time in space-to-depth layout - pixel (y, x) to pixel (y >> 1, x >> 1), channels
                                               s2d_coff + ((y & 1) * 2 + (x & 1)) * cout + c of the half-resolution s2d_tensor - so that the neck
                                               can read the feature map from the grid of its transposed conv's input (plan.py: _neck_up_folds).
+                                              With out_tensor < 0 (kernel 0) ONLY this copy is written: its readers are rtm3d_op_maxpool_s2d, a
+                                              stride-2 conv restated on the copy (stride-1 taps with tap_dc, or kernel 7 with in_s2d) and tap_dc taps.
                                               NOTE for callers that zero-initialise the struct: 0 is a valid tensor id, set -1 for "none". */
     int in_s2d;                            /* kernel 7 only: in_tensor holds the SPACE-TO-DEPTH copy (half resolution, 4 x cin channels at in_coff) of the
                                               map the conv is stated on (Hm, Wm, taps, stride as for the ordinary map) */
@@ -169,6 +171,11 @@ int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor,
 /* z_out = z + sum_i u_i * softmax_{H*W}(u_i)  per (image, channel)
  * (models/nets/keypoint_fpn_fusion.py:60-69).  n_u <= 3.                                         */
 int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_u, const int* u_tensors);
+
+/* 2x2 / stride 2 max-pool (a DLA level's `downsample`, models/nets/dla.py:170-172) of a map that exists only as its space-to-depth
+ * copy (rtm3d_conv_desc.s2d_tensor with out_tensor < 0): the window = the four channel slices of one pixel of in_tensor
+ * (`channels` each, from in_coff); output: `channels` at out_coff of out_tensor, same resolution as in_tensor.                */
+int rtm3d_op_maxpool_s2d(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff, int channels);
 
 /* Replay the plan.  d_in: fp32 NCHW (B,3,H,W) normalised image batch (detect.py:53), or NULL when the input tensor was
  * filled by rtm3d_preprocess_batch (out_mode 1);

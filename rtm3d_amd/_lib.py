@@ -76,6 +76,7 @@ SIGNATURES = {
                                           c_int, c_int, c_size_t]),
     'rtm3d_decode2d_finish': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'rtm3d_op_maxpool': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rtm3d_op_maxpool_s2d': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     'rtm3d_op_softmax_fuse': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     'rtm3d_forward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
     'rtm3d_ctx_set_graph': (c_int, [c_void_p, c_int]),

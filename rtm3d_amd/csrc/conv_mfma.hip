@@ -80,7 +80,7 @@ __device__ __forceinline__ void store_nhwc_tile(const ConvKArgs& a, const ConvGr
                 const auto s1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
                 const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                 if (cw + c * 16 + so < a.cout) {
-                    *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;
+                    if (a.out) *(u32x4*)((f16*)a.out + opix[p] + c * 16 + so) = o;       // (null: only the space-to-depth copy exists)
                     if (a.s2d) *(u32x4*)(a.s2d + spix[p] + c * 16 + so) = o;
                 }
             }
@@ -88,7 +88,7 @@ __device__ __forceinline__ void store_nhwc_tile(const ConvKArgs& a, const ConvGr
 #pragma unroll
             for (int c = 0; c < TC; ++c)
                 if (cw + c * 16 + fk * 4 < a.cout) {
-                    *(f16x4*)((f16*)a.out + opix[p] + c * 16 + fk * 4) = h[c];
+                    if (a.out) *(f16x4*)((f16*)a.out + opix[p] + c * 16 + fk * 4) = h[c];
                     if (a.s2d) *(f16x4*)(a.s2d + spix[p] + c * 16 + fk * 4) = h[c];
                 }
         }

@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolKArgs a) {
     const int n = p / a.Ho;
     f16x8 m;
     bool first = true;
+    if (a.ksize == 0) {
+        // space-to-depth input (rtm3d_op_maxpool_s2d): the 2 x 2 window of full-resolution pixels = the four channel slices of this pixel
+        const f16* ip = a.in + ((size_t)(n * a.in_Hp + oy + a.in_P) * a.in_Wp + ox + a.in_P) * a.in_C + a.in_coff + c8 * 8;
+        m = *(const f16x8*)ip;
+#pragma unroll
+        for (int ph = 1; ph < 4; ++ph) {
+            const f16x8 v = *(const f16x8*)(ip + ph * a.C8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+        first = false;
+    }
     for (int ky = 0; ky < a.ksize; ++ky)
         for (int kx = 0; kx < a.ksize; ++kx) {
             const int iy = oy * a.stride - a.pad + ky + a.in_P, ix = ox * a.stride - a.pad + kx + a.in_P;

@@ -222,10 +222,12 @@ static void* get_blob(rtm3d_ctx* ctx, int id, size_t* bytes) {
 extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     if (!ctx || !d) RT_FAIL("op_conv: null argument");
     Tensor* in = get_tensor(ctx, d->in_tensor);
-    Tensor* out = d->out_nchw_f32 ? nullptr : get_tensor(ctx, d->out_tensor);
+    // (out_tensor < 0 together with s2d_tensor >= 0: only the space-to-depth copy of the output is written)
+    const bool s2d_only = !d->out_nchw_f32 && d->out_tensor < 0 && d->s2d_tensor >= 0;
+    Tensor* out = (d->out_nchw_f32 || s2d_only) ? nullptr : get_tensor(ctx, d->out_tensor);
     Tensor* res = d->res_tensor >= 0 ? get_tensor(ctx, d->res_tensor) : nullptr;
     if (!in) RT_FAIL("op_conv: bad input tensor %d", d->in_tensor);
-    if (!d->out_nchw_f32 && !out) RT_FAIL("op_conv: bad output tensor %d", d->out_tensor);
+    if (!d->out_nchw_f32 && !s2d_only && !out) RT_FAIL("op_conv: bad output tensor %d", d->out_tensor);
     if (d->res_tensor >= 0 && !res) RT_FAIL("op_conv: bad residual tensor %d", d->res_tensor);
     if (d->groups < 1 || d->groups > RT_MAX_GROUPS || d->ntaps < 1 || d->ntaps > RT_MAX_TAPS) RT_FAIL("op_conv: groups/ntaps out of range");
     if (d->out_nchw_f32 < 0 || d->out_nchw_f32 > 4) RT_FAIL("op_conv: out_nchw_f32 out of range");
@@ -266,7 +268,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
             if (d->out_coff[g] < 0 || d->out_coff[g] + d->cout > out->C || (d->out_coff[g] % 8)) RT_FAIL("op_conv: output channel slice out of range");
             if (oyhi >= out->H || oxhi >= out->W || d->out_oy[g] < 0 || d->out_ox[g] < 0) RT_FAIL("op_conv: output pixel out of range");
             if (out->B != in->B) RT_FAIL("op_conv: batch mismatch");
-        } else {
+        } else if (!s2d_only) {
             if (oyhi >= d->out_H || oxhi >= d->out_W) RT_FAIL("op_conv: NCHW output pixel out of range");
         }
         if (res) {
@@ -282,7 +284,8 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     }
     if (d->s2d_tensor >= 0) {
         Tensor* s2 = get_tensor(ctx, d->s2d_tensor);
-        if (!s2 || !out) RT_FAIL("op_conv: bad space-to-depth tensor %d", d->s2d_tensor);
+        if (!s2 || (!out && !s2d_only)) RT_FAIL("op_conv: bad space-to-depth tensor %d", d->s2d_tensor);
+        if (s2d_only && d->kernel != 0) RT_FAIL("op_conv: writing ONLY the space-to-depth copy needs kernel 0");
         if ((d->kernel != 0 && d->kernel != 5) || d->groups != 1 || d->out_scale != 1 || d->out_oy[0] || d->out_ox[0] || (d->Hm & 1) || (d->Wm & 1) || (d->cout % 8))
             RT_FAIL("op_conv: the space-to-depth copy needs kernel 0 or 5, one group, out_scale 1 and an even output height / width");
         if (s2->B != in->B || s2->H * 2 != d->Hm || s2->W * 2 != d->Wm || d->s2d_coff < 0 || d->s2d_coff + 4 * d->cout > s2->C || (d->s2d_coff % 8))
@@ -299,7 +302,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     const double M = (double)a.M;
     op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
     op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0)
-               + (d->s2d_tensor >= 0 ? 2.0 * M * d->cout : 0.0);
+               + (d->s2d_tensor >= 0 && !s2d_only ? 2.0 * M * d->cout : 0.0);
     if (d->kernel == 2) {
         if (d->cin % 64 || d->cout % 256 || d->out_nchw_f32) RT_FAIL("op_conv(mfma256): needs cin %% 64 == 0, cout %% 256 == 0, NHWC output (cin=%d cout=%d)", d->cin, d->cout);
         a.cpt = d->cin / 64; a.ksteps = d->ntaps * a.cpt;
@@ -643,6 +646,26 @@ extern "C" int rtm3d_op_maxpool(rtm3d_ctx* ctx, int in_tensor, int in_coff, int 
     a.ksize = ksize; a.stride = stride; a.pad = pad;
     op.flops = 0;
     op.bytes = 2.0 * in->B * channels * ((double)in->H * in->W + (double)out->H * out->W);
+    ctx->ops.push_back(op);
+    return 0;
+}
+
+extern "C" int rtm3d_op_maxpool_s2d(rtm3d_ctx* ctx, int in_tensor, int in_coff, int out_tensor, int out_coff, int channels) {
+    Tensor* in = ctx ? get_tensor(ctx, in_tensor) : nullptr;
+    Tensor* out = ctx ? get_tensor(ctx, out_tensor) : nullptr;
+    if (!in || !out) RT_FAIL("op_maxpool_s2d: bad tensors");
+    if (channels % 8 || in_coff % 8 || out_coff % 8 || in_coff < 0 || out_coff < 0 || in_coff + 4 * channels > in->C || out_coff + channels > out->C) RT_FAIL("op_maxpool_s2d: bad channel slices (input: 4 x channels)");
+    if (in->H != out->H || in->W != out->W || in->B != out->B) RT_FAIL("op_maxpool_s2d: the space-to-depth copy and the pooled map have one resolution");
+    if (in == out && in_coff < out_coff + channels && out_coff < in_coff + 4 * channels) RT_FAIL("op_maxpool_s2d: output overlaps the input slices");
+    Op op;
+    op.kind = OP_MAXPOOL; op.name = "maxpool_s2d";
+    PoolKArgs& a = op.pool;
+    a.in = in->base; a.out = out->base; a.B = in->B; a.Ho = out->H; a.Wo = out->W; a.C8 = channels / 8;
+    a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_P = in->P; a.in_coff = in_coff;
+    a.out_Hp = out->Hp; a.out_Wp = out->Wp; a.out_C = out->C; a.out_P = out->P; a.out_coff = out_coff;
+    a.ksize = 0; a.stride = 0; a.pad = 0;                       // ksize 0 = the space-to-depth form: max over the four phase slices of one pixel
+    op.flops = 0;
+    op.bytes = 2.0 * in->B * channels * 5.0 * (double)out->H * out->W;
     ctx->ops.push_back(op);
     return 0;
 }

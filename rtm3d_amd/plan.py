@@ -651,21 +651,7 @@ class RealizedPlan(object):
         nfold = self._neck_up_folds(tail) if FOLD_NECK_UP else []
         widen = {f['hs'].tid: 4 * f['Cf'] for f in nfold}    # device tensors that also hold a space-to-depth copy of a backbone feature
         self._s2d_for = {f['feat']: (f['hs'], plan.tensors[f['hs'].tid]['C']) for f in nfold if 'feat' in f}
-        # a level tail whose ordinary output has, besides the folded 1x1 and its own pool, ONE reader that can take the space-to-depth
-        # copy instead (the next level's stride-2 entry on conv64s2_halo.hip) does not write the ordinary copy at all
-        self._in_s2d_for, self._s2d_only = {}, {}
-        for f in nfold:
-            if 'tail' not in f or not S2D_ONLY:
-                continue
-            ro = plan.ops[tail[f['tail']][0]]['out'][0]
-            own = set([f['tail'], f['up'], f['pj']] + list(tail[f['tail']]))
-            readers = [j for j, o in enumerate(plan.ops) if j not in own and self._reads(o, ro.tid) and self._reads_slice(o, ro)]
-            if (len(readers) == 1 and conv64s2_eligible(plan.ops[readers[0]]) and plan.ops[readers[0]].get('variant') is None
-                    and plan.B * (plan.ops[readers[0]]['Hm'] // 4) * (plan.ops[readers[0]]['Wm'] // 32) >= 64
-                    and plan.ops[readers[0]]['inp'][0].coff == ro.coff and readers[0] not in folds_pre(self)):
-                f['s2d_only'] = True
-                self._in_s2d_for[readers[0]] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
-                self._s2d_only[(ro.tid, ro.coff, ro.C)] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
+        self._plan_s2d_only(nfold, tail)
         for i, t in enumerate(plan.tensors):
             tid = ctypes.c_int()
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'] + widen.get(i, 0), t['pad'], ctypes.byref(tid)), 'tensor_create')
@@ -707,10 +693,68 @@ class RealizedPlan(object):
                 continue
             if k in folded_by:
                 op = folded_by[k]
+            if k in self._s2d_readers:
+                kind, hs_, base_, cf_ = self._s2d_readers[k]
+                if kind == 'pool':
+                    _lib.check(self.lib.rtm3d_op_maxpool_s2d(self.ctx, self.tids[hs_.tid], base_, self.tids[op['out'].tid], op['out'].coff, cf_), 'op_maxpool_s2d ' + op['name'])
+                    self.op_names.append(op['name'])
+                    continue
+                op = self._s2d_input_conv(op, hs_, base_, cf_)
             if k in neck_by:
                 op = self._neck_fold_conv(neck_by[k])
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
+
+    def _plan_s2d_only(self, nfold, tail):
+        """Which feature maps exist ONLY as their space-to-depth copy, and how their remaining readers take it (sets self._in_s2d_for,
+        self._s2d_only, self._s2d_readers, self._s2d_only_producers; marks the folds)."""
+        plan = self.plan
+        # a level tail whose ordinary output has, besides the folded 1x1 and its own pool, ONE reader that can take the space-to-depth
+        # copy instead (the next level's stride-2 entry on conv64s2_halo.hip) does not write the ordinary copy at all
+        self._in_s2d_for, self._s2d_only = {}, {}
+        for f in nfold:
+            if 'tail' not in f or not S2D_ONLY:
+                continue
+            ro = plan.ops[tail[f['tail']][0]]['out'][0]
+            own = set([f['tail'], f['up'], f['pj']] + list(tail[f['tail']]))
+            readers = [j for j, o in enumerate(plan.ops) if j not in own and self._reads(o, ro.tid) and self._reads_slice(o, ro)]
+            if (len(readers) == 1 and conv64s2_eligible(plan.ops[readers[0]]) and plan.ops[readers[0]].get('variant') is None
+                    and plan.B * (plan.ops[readers[0]]['Hm'] // 4) * (plan.ops[readers[0]]['Wm'] // 32) >= 64
+                    and plan.ops[readers[0]]['inp'][0].coff == ro.coff and readers[0] not in folds_pre(self)):
+                f['s2d_only'] = True
+                self._in_s2d_for[readers[0]] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
+                self._s2d_only[(ro.tid, ro.coff, ro.C)] = (f['hs'], plan.tensors[f['hs'].tid]['C'])
+        # likewise a plain conv on the 128-pixel kernel (DLA level3 / level4 roots): every other reader of its output must be a 2x2 / 2
+        # max-pool (-> rtm3d_op_maxpool_s2d) or a stride-2 conv with taps within +-1 (-> the same conv restated on the copy)
+        self._s2d_readers, self._s2d_only_producers = {}, set()
+        for f in nfold:
+            if 'feat' not in f or not S2D_ONLY or conv64_eligible(plan.ops[f['feat']]):
+                continue
+            ro = plan.ops[f['feat']]['out'][0]
+            own = {f['feat'], f['up'], f['pj']}
+            readers = [j for j, o in enumerate(plan.ops) if j not in own and self._reads(o, ro.tid) and self._reads_slice(o, ro)]
+            plan_ = {}
+            for j in readers:
+                o = plan.ops[j]
+                same = lambda sl: sl.tid == ro.tid and sl.coff == ro.coff and sl.C == ro.C
+                if o['op'] == 'maxpool' and o['k'] == 2 and o['stride'] == 2 and o['pad'] == 0 and same(o['inp']):
+                    plan_[j] = 'pool'
+                elif (o['op'] == 'conv' and o['groups'] == 1 and o['in_stride'] == 2 and o['out_scale'] == 1 and same(o['inp'][0]) and o['cin'] % 64 == 0
+                      and all(abs(dy) <= 1 and abs(dx) <= 1 for dy, dx in o['taps'][0]) and o.get('variant') is None and 'tap_dc' not in o
+                      and (o['res'][0] is None or o['res'][0].tid != ro.tid) and j not in folds_pre(self)
+                      and len(o['taps'][0]) * (o['cin'] // 64) <= _lib.MAX_TAPS and not conv64s2_eligible(o)):
+                    plan_[j] = 'conv'
+                else:
+                    plan_ = None
+                    break
+            if plan_ is None:
+                continue
+            f['s2d_only'] = True
+            self._s2d_only_producers.add(f['feat'])
+            base = plan.tensors[f['hs'].tid]['C']
+            for j, kind in plan_.items():
+                self._s2d_readers[j] = (kind, f['hs'], base, f['Cf'])
+            self._s2d_only[(ro.tid, ro.coff, ro.C)] = (f['hs'], base)
 
     @classmethod
     def rewrites_only(cls, plan):
@@ -817,6 +861,23 @@ class RealizedPlan(object):
                 'Hm': D['Hm'], 'Wm': D['Wm'], 'in_stride': 1, 'out_scale': 2, 'cin': 64, 'cout': 256, 'groups': 4, 'taps': taps, 'tap_dc': dcs,
                 'out_off': list(D['out_off']), 'relu': False, 'w': w, 'bias': np.tile(bias.astype(np.float32)[None], (4, 1)), 'out_nchw': 0,
                 'out_hw': (2 * D['Hm'], 2 * D['Wm'])}
+
+    @staticmethod
+    def _s2d_input_conv(op, hs, base, Cf):
+        """A stride-2 conv (taps within +-1) restated on the space-to-depth copy of its input - full-resolution pixel (2y + d, 2x + e)
+        is half-resolution pixel (y + d // 2, x + e // 2), phase (d % 2, e % 2) - as a STRIDE-1 conv over 64-channel pseudo-taps
+        (tap_dc): same products, same order within a tap."""
+        cout, cpt = op['cout'], op['cin'] // 64
+        taps, w = op['taps'][0], op['w'][0]                                  # (taps, cout, cin)
+        wt = np.zeros((len(taps) * cpt, cout, 64), np.float32)
+        tl, dc = [], []
+        for t, (dy, dx) in enumerate(taps):
+            for q in range(cpt):
+                wt[t * cpt + q] = w[t][:, q * 64:(q + 1) * 64]
+                tl.append((dy // 2, dx // 2)); dc.append(base + ((dy % 2) * 2 + (dx % 2)) * Cf + q * 64)
+        new = dict(op)
+        new.update(cin=64, in_stride=1, taps=[tl], tap_dc=[dc], w=wt[None], inp=[Slice(hs.tid, 0, 64)], name=op['name'] + '[s2d]')
+        return new
 
     def _project_folds(self):
         """{index of a block's second conv: index of the `project` 1x1 that produces its residual} where the 1x1 (no ReLU, stride
@@ -1106,6 +1167,8 @@ class RealizedPlan(object):
             # this conv's output feeds a neck up-fold: second copy in space-to-depth layout, 128-pixel kernel (the one whose epilogue has it)
             d.s2d_tensor, d.s2d_coff = self.tids[s2d[0].tid], s2d[1]
             variant = 5 if conv64_eligible(op) else 0
+            if self._k in getattr(self, '_s2d_only_producers', ()):
+                d.out_tensor = -1                 # every reader takes the copy: the ordinary output is not written
         if variant is None:
             variant = (5 if conv64_eligible(op) else 7 if conv64s2_eligible(op) and self.plan.B * (op['Hm'] // 4) * (op['Wm'] // 32) >= 64
                        else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)

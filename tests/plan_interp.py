@@ -73,6 +73,17 @@ def run_plan(plan, x_nchw, half=False, prefill=None, yx=None):
                 for px in range(2):
                     c0 = op['coff'] + (py * 2 + px) * src.C
                     dbuf[:, Pd:Pd + Hs // 2, Pd:Pd + Ws // 2, c0:c0 + src.C] = v[:, py::2, px::2]
+        elif op['op'] == 'zero_slice':
+            # (test only: the ordinary copy of a feature that exists only as its space-to-depth copy on the device)
+            sl = op['slice']
+            bufs[sl.tid][..., sl.coff:sl.coff + sl.C] = 0
+        elif op['op'] == 'maxpool_s2d':
+            # rtm3d_op_maxpool_s2d: max over the four phase slices of one pixel
+            ibuf, Pi = bufs[op['tid']], plan.tensors[op['tid']]['pad']
+            o = op['out']
+            obuf, Po, Ho, Wo = view(o)
+            v = torch.stack([ibuf[:, Pi:Pi + Ho, Pi:Pi + Wo, op['coff'] + ph * o.C: op['coff'] + (ph + 1) * o.C] for ph in range(4)], 0).max(0).values
+            obuf[:, Po:Po + Ho, Po:Po + Wo, o.coff:o.coff + o.C] = v
         elif op['op'] == 'headout':
             i = op['inp']
             ibuf, Pi, Hi, Wi = view(i)

@@ -44,6 +44,7 @@ def test_realize_level_rewrites_keep_the_function(bb):
         tail = R._level_tail_chains()
         nfold = R._neck_up_folds(tail)
         folds = R._project_folds()
+        R._plan_s2d_only(nfold, tail)
     finally:
         plan_mod.V2_MIN_TILES = v2_min
     if bb == 'DLA-34':
@@ -61,24 +62,43 @@ def test_realize_level_rewrites_keep_the_function(bb):
     for f in nfold:
         prod = tail[f['tail']][0] if 'tail' in f else f['feat']          # the op that writes the feature (the root of a fused tail, or a conv)
         copy_after[prod] = {'op': 's2d_copy', 'src': P.ops[prod]['out'][0], 'tid': f['hs'].tid, 'coff': P.tensors[f['hs'].tid]['C']}
+    # features that exist only as their space-to-depth copy: the ordinary copy is wiped right after the copy is made, the readers
+    # are rewritten exactly as the device path rewrites them (a reader of the ordinary copy would then see zeros)
+    wipe_after = {}
+    for f in nfold:
+        if f.get('s2d_only'):
+            prod = tail[f['tail']][0] if 'tail' in f else f['feat']
+            wipe_after[prod] = {'op': 'zero_slice', 'slice': P.ops[prod]['out'][0]}
+    if bb == 'DLA-34':
+        assert len(wipe_after) == 2 and len(R._s2d_readers) == 4, (wipe_after.keys(), R._s2d_readers)     # level3 / level4 roots: pool + entry conv each
     ops = []
     for k, op in enumerate(P.ops):
         if k in skip:
             continue
         if k in folds:
             op = R._folded_conv(P.ops[k], P.ops[folds[k]])
+        if k in R._s2d_readers:
+            kind, hs_, base_, cf_ = R._s2d_readers[k]
+            op = {'op': 'maxpool_s2d', 'tid': hs_.tid, 'coff': base_, 'out': op['out']} if kind == 'pool' else R._s2d_input_conv(op, hs_, base_, cf_)
         if k in neck_by:
             op = R._neck_fold_conv(neck_by[k])
             assert len(op['taps'][0]) == 16 + neck_by[k]['Cf'] // 64 and op['cin'] == 64
         ops.append(op)
         if k in copy_after:
             ops.append(copy_after[k])
+        if k in wipe_after:
+            ops.append(wipe_after[k])
     Q.ops = ops
-    assert len(Q.ops) == len(P.ops) - len(folds)                          # project ops gone; each neck fold: -2 ops + 1 copy op
+    assert len(Q.ops) == len(P.ops) - len(folds) + len(wipe_after)        # project ops gone; each neck fold: -2 ops + 1 copy op
     outs1, fetch1 = run_plan(Q, x)
     np.testing.assert_allclose(fetch1(P.named['z']).numpy(), fetch0(P.named['z']).numpy(), atol=2e-5, rtol=1e-5)
+    wiped = {(w['slice'].tid, w['slice'].coff) for w in wipe_after.values()}
     for i in range(4):
-        np.testing.assert_allclose(fetch1(P.named['feat%d' % i]).numpy(), fetch0(P.named['feat%d' % i]).numpy(), atol=1e-5, rtol=1e-5)
+        sl = P.named['feat%d' % i]
+        if (sl.tid, sl.coff) in wiped:
+            assert float(fetch1(sl).abs().max()) == 0.0
+            continue
+        np.testing.assert_allclose(fetch1(sl).numpy(), fetch0(sl).numpy(), atol=1e-5, rtol=1e-5)
     for a, b in zip(outs1, outs0):
         np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-5, rtol=1e-5)
 

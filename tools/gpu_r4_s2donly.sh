@@ -7,5 +7,5 @@ tail -8 gpurun_out/r4_s2donly_test.log
 if [ $rc -ne 0 ]; then exit 1; fi
 for v in 1 0 1 0; do
   export RTM3D_S2D_ONLY=$v
-  timeout -k 10 120 python tools/gpu_variants.py rtm3d_amd/_C/librtm3d_hip.so "level2.tree2.conv2|level3.tree1.tree1.conv1" 2>/dev/null | sed "s/^_C /s2d_only=$v /" || exit 1
+  timeout -k 10 120 python tools/gpu_variants.py rtm3d_amd/_C/librtm3d_hip.so "level2.tree2.conv2|level3.tree2.root|level4.tree2.root|level[45].downsample|level4.tree1.tree1.conv1|level5.tree1.conv1" 2>/dev/null | sed "s/^_C /s2d_only=$v /" || exit 1
 done
