@@ -94,6 +94,16 @@ struct SoftmaxKArgs {
     int partial_chunks;            // > 0: `partial` was written by the producers' epilogues with this many chunks per image
 };
 
+// Workgroup b of an n-workgroup launch runs on XCD b % 8 (round-robin dispatch).  Index of the work item it should take so that
+// every XCD walks a CONTIGUOUS eighth of the items (a bijection on [0, n) for any n): items that share input land in one L2.
+__device__ __forceinline__ int xcd_contiguous_index(int b, int n) {
+#ifdef RT_TIMING_NO_XCD_ORDER
+    return b;
+#endif
+    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + k;
+}
+
 struct HeadOutArgs {
     const f16* in;          // h2: padded NHWC, 4 x 256 channels
     const f16* wgt;         // [head][tap][chunk*2+kk][lane][8]  (16 output rows, zero padded)
@@ -103,7 +113,7 @@ struct HeadOutArgs {
     int nheads;
     int B, H, W;
     int in_Hp, in_Wp, in_C, in_P;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, tile_rows;   // tile_rows: 8 or 16
 };
 
 struct StemFusedArgs {

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(const StemFusedArgs 
 #pragma unroll
     for (int s = 0; s < 5; ++s) wl[s] = SF_WLOAD(a.w_l0 + (s * 64 + lane) * 8);
     const f32x4 bb = *(const f32x4*)(a.b_base + fk * 4), bl = *(const f32x4*)(a.b_l0 + fk * 4);
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous_index(blockIdx.x, gridDim.x);   // neighbouring tiles (overlapping image windows) through one L2
     const int n = tile / tpi, r0 = tile - n * tpi;
     const int ty = r0 / a.tiles_x, tx = r0 - ty * a.tiles_x;
     const int y0 = ty * SF_TH, x0 = tx * SF_TW;

@@ -622,7 +622,9 @@ extern "C" int rtm3d_op_headout(rtm3d_ctx* ctx, int in_tensor, int w_blob, int b
     a.nheads = nheads;
     a.B = in->B; a.H = in->H; a.W = in->W;
     a.in_Hp = in->Hp; a.in_Wp = in->Wp; a.in_C = in->C; a.in_P = in->P;
-    a.tiles_x = (in->W + 31) / 32; a.tiles_y = (in->H + 7) / 8;
+    // 16-row tiles (less halo) once they still give every CU its two workgroups twice over, 8-row tiles for small batches
+    a.tile_rows = (long long)in->B * ((in->H + 15) / 16) * ((in->W + 31) / 32) * nheads >= 4LL * ctx->n_cus ? 16 : 8;
+    a.tiles_x = (in->W + 31) / 32; a.tiles_y = (in->H + a.tile_rows - 1) / a.tile_rows;
     op.flops = 2.0 * in->B * in->H * in->W * 9.0 * 256.0 * csum;
     op.bytes = (double)in->B * in->H * in->W * (256.0 * nheads * 2 + csum * 4.0);
     ctx->ops.push_back(op);
@@ -688,16 +690,18 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
         if (!u || u->C != 256 || u->H != zi->H || u->W != zi->W || u->B != zi->B) RT_FAIL("op_softmax_fuse: u tensor %d mismatch", i);
         a.u[i] = u->base; a.u_Hp[i] = u->Hp; a.u_Wp[i] = u->Wp; a.u_C[i] = u->C; a.u_P[i] = u->P;
     }
-    // one workgroup per (image, chunk): two rows at the batch sizes the path is quoted on.  Small batches: single rows, and
-    // the apply pass (which does not touch the partials) also cuts rows into column segments until the launch has about
-    // two workgroups per CU (bs=1: 48 workgroups -> 384)
+    // statistics pass: one workgroup per (image, chunk): two rows at the batch sizes the path is quoted on, single rows for small batches
     const bool small = (long long)a.B * ((a.H + 1) / 2) < 2LL * ctx->n_cus;
     a.rows_per_chunk = small ? 1 : 2;
     a.chunks = (a.H + a.rows_per_chunk - 1) / a.rows_per_chunk;
-    a.apply_rows = a.rows_per_chunk; a.xsplit = 1;
-    while ((long long)a.B * a.chunks * a.xsplit < 2LL * ctx->n_cus && a.xsplit < 8 && a.W / (a.xsplit * 2) >= 32) a.xsplit *= 2;
+    // the apply pass (which does not touch the partials) runs one row per workgroup, rows cut into up to four column segments of
+    // >= 64 pixels (same box, bs=32: 0.503 ms with two full rows per workgroup, 0.495 with one, 0.483 with quarter rows), and
+    // into more (up to eight, >= 32 pixels) until a small batch has about two workgroups per CU (bs=1: 48 workgroups -> 384)
+    a.apply_rows = 1; a.xsplit = 1;
+    while (a.xsplit < 4 && a.W / (a.xsplit * 2) >= 64) a.xsplit *= 2;
+    while ((long long)a.B * a.H * a.xsplit < 2LL * ctx->n_cus && a.xsplit < 8 && a.W / (a.xsplit * 2) >= 32) a.xsplit *= 2;
     a.seg_w = ((a.W + a.xsplit - 1) / a.xsplit + 7) / 8 * 8;
-    a.apply_chunks = a.chunks * a.xsplit;
+    a.apply_chunks = a.H * a.xsplit;
     // partials already emitted by the producers' epilogues (rtm3d_conv_desc.softmax_stat_slot)?
     bool emitted = ctx->stat_buf != nullptr && ctx->stat_B == a.B;
     for (int i = 0; i < n_u && emitted; ++i) emitted = ctx->stat_tensor[i] == u_tensors[i];
