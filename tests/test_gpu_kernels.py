@@ -287,8 +287,9 @@ def test_stem_and_headout_vs_torch():
         (got,), _ = _run(P, [], [yt], x_img=x)
         ref = h(F.conv2d(h(x), h(torch.from_numpy(w)), torch.from_numpy(b), stride, 3).relu()).numpy()
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
-    # the four logit convs (halo-tile kernel), sizes that are not multiples of the 8x32 tile
-    for (Hh, Wh) in ((8, 40), (11, 37), (16, 64)):
+    # the four logit convs (halo-tile kernel), sizes that are not multiples of the 8x32 tile; the last case is large enough
+    # (batch x tiles x heads >= 4 x CUs) to take the 16-row tiles, with a ragged last tile row and column
+    for (B, Hh, Wh) in ((2, 8, 40), (2, 11, 37), (2, 16, 64), (44, 27, 70)):
         P = plan_mod.Plan(B, Hh * 4, Wh * 4)
         ht = P.tensor(Hh, Wh, 1024, 1)
         ws = [(rng.standard_normal((c, 256, 3, 3)) / 48).astype(np.float32) for c in (3, 16, 2, 2)]
