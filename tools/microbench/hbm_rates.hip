@@ -40,6 +40,23 @@ __global__ __launch_bounds__(256) void k_rw(const u32x4* __restrict__ a, const u
     }
 }
 
+// every workgroup re-reads its own 16 KB x UNROLL.. region `reps` times in ONE launch: what a CU can take in from its XCD's L2
+template <int NT>
+__global__ __launch_bounds__(256) void k_reread(const u32x4* __restrict__ p, size_t per_wg, int reps, unsigned* out) {
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4* q = p + (size_t)blockIdx.x * per_wg;
+    for (int r = 0; r < reps; ++r)
+        for (size_t i = threadIdx.x; i + 768 < per_wg; i += 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = NT ? __builtin_nontemporal_load(q + i + u * 256) : q[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc ^= v[u];
+            asm volatile("" : "+v"(acc));
+        }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = 1;
+}
+
 int main() {
     const size_t bytes = (size_t)512 << 20, n = bytes / 16;
     u32x4 *buf[5]; unsigned* out;
@@ -65,6 +82,22 @@ int main() {
         timeit("copy  (1 read + 1 write)", 2 * G, [&] { hipLaunchKernelGGL((k_rw<1>), dim3(grid), dim3(256), 0, 0, buf[0], buf[1], buf[2], buf[3], buf[4], n); });
         timeit("2 reads + 1 write", 3 * G, [&] { hipLaunchKernelGGL((k_rw<2>), dim3(grid), dim3(256), 0, 0, buf[0], buf[1], buf[2], buf[3], buf[4], n); });
         timeit("4 reads + 1 write", 5 * G, [&] { hipLaunchKernelGGL((k_rw<4>), dim3(grid), dim3(256), 0, 0, buf[0], buf[1], buf[2], buf[3], buf[4], n); });
+    }
+    // where the bytes come from: the same sweep over 16 MB (each XCD re-reads its own 2 MB share: L2), 128 MB (Infinity Cache), 512 MB
+    for (size_t mb : {16, 128, 512}) {
+        const size_t nn = (mb << 20) / 16;
+        char name[64];
+        snprintf(name, sizeof name, "read  nt  4 x 16 B, %zu MB swept 8 times", mb);
+        timeit(name, 8.0 * (mb << 20) / 1e9, [&] { for (int r = 0; r < 8; ++r) hipLaunchKernelGGL((k_read<1, 4>), dim3(2048), dim3(256), 0, 0, buf[0], nn, out); });
+        snprintf(name, sizeof name, "read  plain 4 x 16 B, %zu MB swept 8 times", mb);
+        timeit(name, 8.0 * (mb << 20) / 1e9, [&] { for (int r = 0; r < 8; ++r) hipLaunchKernelGGL((k_read<0, 4>), dim3(2048), dim3(256), 0, 0, buf[0], nn, out); });
+    }
+    for (int wgs : {256, 1024, 2048}) {
+        // 16 MB in all (2 MB per XCD), 64 passes in one launch
+        const size_t per_wg = ((size_t)16 << 20) / 16 / wgs;
+        char name[96];
+        snprintf(name, sizeof name, "L2 re-read, %d workgroups x %zu KB x 64 passes", wgs, per_wg * 16 >> 10);
+        timeit(name, 64.0 * (16 << 20) / 1e9, [&] { hipLaunchKernelGGL((k_reread<0>), dim3(wgs), dim3(256), 0, 0, buf[0], per_wg, 64, out); });
     }
     return 0;
 }
