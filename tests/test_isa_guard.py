@@ -72,7 +72,7 @@ def test_no_spills_no_scratch(isa_files):
 def test_m0_only_inside_the_dma_macro(isa_files):
     """Per kernel function: if inline asm writes m0 (the DMA macro), then NOTHING else in that function may mention m0 -
     neither compiler-generated code (e.g. the m0 the compiler sets up for __builtin_amdgcn_global_load_lds, s_movrel,
-    v_readlane ..., m0) nor another asm form.  Kernels that leave m0 to the compiler (conv_headout: the builtin) are free."""
+    v_readlane ..., m0) nor another asm form.  Kernels that leave m0 to the compiler (the generic conv_mfma_kernel: the builtin) are free."""
     asm_kernels = 0
     for fname, text in isa_files.items():
         body = text.split('.amdgpu_metadata')[0]
