@@ -458,6 +458,8 @@ extern "C" int rtm3d_op_stem_fused(rtm3d_ctx* ctx, int x4_tensor, int out_tensor
     if (x->C != 4 || x->P < 4) RT_FAIL("op_stem_fused: the input must be the NHWC4 image tensor with a border >= 4");
     if (o->H * sc != x->H || o->W * sc != x->W || o->B != x->B || out_coff < 0 || out_coff + oc > o->C || (out_coff % 8)) RT_FAIL("op_stem_fused: output slice mismatch");
     if (x->H % 16 || x->W % 32) RT_FAIL("op_stem_fused: needs H %% 16 == 0 and W %% 32 == 0 (got %dx%d)", x->H, x->W);
+    // the kernel addresses one image (3 fp32 planes) through a buffer descriptor with 32-bit byte offsets
+    if ((long long)x->H * x->W * 3 * 4 >= (1LL << 31)) RT_FAIL("op_stem_fused: image of %dx%d exceeds the 2 GiB the stem addresses per image", x->H, x->W);
     size_t wb = 0, bb = 0, wl = 0, bl = 0, w1b = 0, b1b = 0;
     const f16* w0 = (const f16*)get_blob(ctx, w_base_blob, &wb);
     const float* b0 = (const float*)get_blob(ctx, b_base_blob, &bb);
