@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void softmax_combine_kernel(const SoftmaxKArg
 }
 
 // pass 3: z_out = z_in + sum_i u_i * exp(u_i - M_i) / S_i      (16-byte lanes, two pixels in flight per lane)
-// Round 4, same-box timing builds: without the exponentials 0.496 vs 0.497 ms (the pass is memory-bound: 2.0 GB at 4.1-4.4 TB/s,
+// Round 4, same-box timing builds: without the exponentials 0.496 vs 0.497 ms (the pass is memory-bound: 2.0 GB read + 0.5 GB written at 5.2-5.4 TB/s,
 // four read streams and one write stream); one pixel per lane and step with the next step's loads issued before the arithmetic
 // 0.539 vs 0.528; 8-byte lanes (4 channels per lane, 124 registers, four waves per SIMD) 0.483 vs 0.479; smaller workgroup shares help
 // a little (runtime.hip: one row cut into four segments per workgroup, -4 %).  A plain 4-reads-1-write kernel on 512 MB streams gets
