@@ -20,6 +20,26 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA issued from inline asm: the ONE definition every pipelined conv kernel uses (m0 = LDS byte address of the wave's
+// 1 KB run, one 16-byte piece per lane).  Why asm: the compiler must not know these write LDS - its waitcnt pass treats every
+// visible ds_read as possibly aliasing a pending LDS-DMA and drains vmcnt(0) in front of it; ordering against the DMA is each
+// kernel's counted `s_waitcnt vmcnt(N)` + barrier.
+// m0 is a RESERVED register: the compiler does not promise to honour it in a clobber list (it says so: -Winline-asm "clobber
+// list contains reserved registers", silenced for exactly the translation units that use these macros: Makefile, DMA_TUS).
+// The idiom is sound because m0 is written and consumed inside ONE asm statement, so its value never has to survive outside
+// it, AND because the compiler's own code in those kernels never touches m0: tests/test_isa_guard.py::
+// test_m0_only_inside_the_dma_macro reads the generated ISA of every kernel and FAILS if a kernel that uses these macros
+// contains any other mention of m0 (compiler-emitted or hand-written).  A toolchain upgrade that changes this shows up there.
+#define RT_DMA16(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+// non-temporal form (single-read streams)
+#define RT_DMA16_NT(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+// wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane (no 64-bit address registers)
+#define RT_DMA16_SBASE(voff_bytes, sbase, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
+
 #define RT_MAX_GROUPS 4
 #define RT_MAX_TAPS 80
 

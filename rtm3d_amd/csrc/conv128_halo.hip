@@ -41,8 +41,7 @@
 
 #define LDS_AS __attribute__((address_space(3)))
 #define C128_NSW 3
-#define C128_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define C128_DMA16 RT_DMA16                         // common.h: the one LDS-DMA definition
 #define C128_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 template <int RES>

@@ -18,8 +18,7 @@
 #define S2_PIECES (S2_HH * S2_HW * 4)              // 4420 16-byte pieces
 #define S2_NDMA 9                                  // DMA instructions per wave and tile (9 x 512 lanes >= 4420)
 #define S2_BUF_PIECES (S2_NDMA * 512)
-#define S2_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define S2_DMA16 RT_DMA16                           // common.h: the one LDS-DMA definition
 #define S2_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 __global__ __launch_bounds__(512) void conv32s2_fused_kernel(const Conv32S2Args a, unsigned int* ticket_ctr, const int single) {

@@ -30,8 +30,7 @@
 #define C64_HALO_W 34
 #define C64_HALO_PIECES (10 * C64_HALO_W * 8)      // 2720 16-byte pieces per halo
 #define C64_BUF_PIECES 3072                        // 6 DMA instructions x 512 lanes (the overrun re-stages the last piece)
-#define C64_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define C64_DMA16 RT_DMA16                          // common.h: the one LDS-DMA definition
 #define C64_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 template <int RES, int S2D>

@@ -33,8 +33,7 @@
 #define C64_BUF_PIECES 3072                        // 6 DMA instructions x 512 lanes (the overrun re-stages the last piece)
 #define CR_W_PIECES 1024                           // root weights: [4 output tiles][4 K-steps][64 lanes] 16-byte fragments
 #define CR_X_PIECES 2048                           // exchange area: [8 waves][4 fragments][64 lanes]
-#define C64_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define C64_DMA16 RT_DMA16                          // common.h: the one LDS-DMA definition
 #define C64_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define C64_LDS_F16X8_W(byte_addr) (*(LDS_AS f16x8*)(uintptr_t)(byte_addr))
 

@@ -29,8 +29,7 @@
 #define S2_HALO_PIECES (S2_HALO_H * S2_HALO_W * 8)          // 4680 16-byte pieces per halo
 #define S2_BUF_PIECES (((S2_HALO_PIECES + 63) / 64) * 64)   // 4736
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane (no 64-bit address registers)
-#define S2_DMA16(voff_bytes, sbase, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
+#define S2_DMA16 RT_DMA16_SBASE                     // common.h: the one LDS-DMA definition
 #define S2_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 __global__ __launch_bounds__(512) void conv64s2_halo_kernel(const ConvKArgs a, unsigned int* ticket_ctr, const int single) {

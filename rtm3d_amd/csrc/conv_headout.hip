@@ -29,8 +29,7 @@
 #endif
 #define HO_TW 32
 #define HO_HW (HO_TW + 2)                 // halo row pitch in pixels
-#define HO_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define HO_DMA16 RT_DMA16                           // common.h: the one LDS-DMA definition
 
 // Round 4: the 256 input channels of a head are walked in EIGHT 32-channel half chunks through two 24 KB buffers: the DMA of
 // half chunk h + 1 is in flight while h is multiplied (the former form staged a 64-channel chunk into one 44 KB buffer, waited,

@@ -243,8 +243,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 //     usual epilogue.  No second launch.
 // Same operand maps, weight packing and epilogue as conv_mfma_kernel: bit-identical results when ksplit == 1.
 #define DEEP_NS 4
-#define DEEP_DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define DEEP_DMA16 RT_DMA16                         // common.h: the one LDS-DMA definition
 
 template <int BN, int RES>
 __global__ __launch_bounds__(256) void conv_mfma_deep_kernel(const ConvKArgs a, unsigned int* tile_ctr) {

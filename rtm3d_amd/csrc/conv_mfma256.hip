@@ -240,10 +240,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // the DMA is SEG_SYNC_N's counted vmcnt + barrier.  The operand reads stay ordinary loads so that the hazard
 // recogniser sees them (with the reads hidden in asm instead, a renamed accumulator's old registers can be
 // handed to a ds_read whose data lands before a queued MFMA has read them as SrcC: conv_mfma256_halo.hip).
-#define DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
-#define DMA16_NT(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define DMA16 RT_DMA16                              // common.h: the one LDS-DMA definition
+#define DMA16_NT RT_DMA16_NT
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LOAD_X_N(SLOT)                                                                      \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \

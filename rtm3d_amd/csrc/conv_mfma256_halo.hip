@@ -44,8 +44,7 @@ struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 // the DMA is SEG_SYNC's counted vmcnt + barrier.  The operand reads stay ordinary loads, so that the hazard
 // recogniser sees them: with the reads hidden in asm instead, the register allocator handed a renamed
 // accumulator's old registers to a ds_read whose data landed before a queued MFMA had read them as SrcC.
-#define DMA16(gptr, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
+#define DMA16 RT_DMA16                              // common.h: the one LDS-DMA definition
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LDS_F32X4(byte_addr) (*(const LDS_AS f32x4*)(uintptr_t)(byte_addr))
 

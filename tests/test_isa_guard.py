@@ -30,12 +30,16 @@ def isa_files():
     import shutil
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not (os.path.exists(hipcc) or shutil.which(hipcc)):
-        pytest.skip('no hipcc (%s): the ISA guard needs the compiler' % hipcc)
+        # a FAILURE, not a skip: this guard is what stands in for the m0 clobber the compiler does not honour (common.h, RT_DMA16);
+        # a box that cannot run it must not report the suite green
+        pytest.fail('no hipcc (%s): the ISA guard needs the compiler (set HIPCC)' % hipcc)
     r = subprocess.run(['make', '-C', CSRC, '-j8', 'isa'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
-        # (the compiler's diagnostics, not a bare CalledProcessError; the -Winline-asm notes about m0 are filtered out)
-        tail = [ln for ln in r.stdout.splitlines() if 'Winline-asm' not in ln and 'expanded from macro' not in ln and 'clobber' not in ln]
-        pytest.fail('`make isa` failed (rc %d):\n%s' % (r.returncode, '\n'.join(tail[-60:])))
+        pytest.fail('`make isa` failed (rc %d):\n%s' % (r.returncode, '\n'.join(r.stdout.splitlines()[-60:])))
+    # the build is warning-free since round 5 (-Wno-inline-asm for the LDS-DMA translation units only, Makefile DMA_TUS): any
+    # diagnostic is news
+    warns = [ln for ln in r.stdout.splitlines() if 'warning:' in ln]
+    assert not warns, 'compiler warnings in `make isa`:\n%s' % '\n'.join(warns[:20])
     files = sorted(f for f in os.listdir(ISA) if f.endswith('.s'))
     srcs = sorted(f[:-4] + '.s' for f in os.listdir(CSRC) if f.endswith('.hip'))
     assert files == srcs, (files, srcs)
