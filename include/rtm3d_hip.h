@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 7
+#define RTM3D_ABI_VERSION 8
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 80
 
@@ -197,6 +197,10 @@ int rtm3d_ctx_set_graph(rtm3d_ctx* ctx, int enable);
 /* TEST HOOK for the rule above: enable != 0 puts one hipMemsetAsync in front of every replay, so that a capture holds a memset
  * node and must be refused (tests/test_gpu_kernels.py::test_graph_with_memset_node_is_refused).  Never set by the product.  */
 int rtm3d_ctx_debug_memset_in_replay(rtm3d_ctx* ctx, int enable);
+/* DIAGNOSTICS, unsupported: copies n 32-bit words, starting at word `offset`, of the context's debug area to the host (after a
+ * device synchronisation).  Only diagnostic builds of the library write there (-DC256_STAMPS: in-kernel s_memtime stamps of the
+ * persistent 256 x 256 convolution, tools/gpu_c256_stamps.sh); in the product build the words read zero.                   */
+int rtm3d_ctx_debug_read_words(rtm3d_ctx* ctx, int offset, int n, unsigned int* h_out);
 /* Graph bookkeeping of a context: captures made, replays served from the cache, whether graph mode is still on (a caller that
  * hands over fresh buffers on every call makes every call a capture; after 32 captures without as many hits the context gives
  * up on graphs - Model.forward_logits(out=...) keeps the addresses stable).  Any pointer may be NULL.                      */
@@ -267,10 +271,19 @@ int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_ver
 
 /* Same solver over the fixed-size slots written by rtm3d_decode2d, without a host round trip:
  * slot i = (image i / topk, rank i % topk) is solved iff rank < d_n[image]; other slots get
- * status -1 and are otherwise untouched.  d_K_per_image[B*9].  Outputs have B*topk rows.          */
+ * status -1 and are otherwise untouched.  d_K_per_image[B*9].  Outputs have B*topk rows.
+ * form (ABI 8) selects the search direction of the wave-cooperative solver on this, the product path:
+ *   RTM3D_SOLVER_DIRECT     two-loop recursion over the stored pairs (rtm3d_decode3d's arithmetic; the cheaper one);
+ *   RTM3D_SOLVER_PUBLISHED  L-BFGS-B 3.0's published subspace step (formk / subsm / formt) - the arithmetic SciPy runs behind
+ *                           utils/model_utils.py:295-296; bit-identical to rtm3d_decode3d_reference_form, ~2.4x the cycles per
+ *                           iteration and 67 KB of LDS per 8-object workgroup (+0.16 ms per bs=32 step at ~470 objects).
+ * On identical inputs both agree with the reference's SciPy results on keep / reject; kept boxes: published form 100 % within
+ * 1e-4 on every fixture, direct form 99.1-100 % (one object in ~1000 ends an iteration apart).          */
+#define RTM3D_SOLVER_DIRECT 0
+#define RTM3D_SOLVER_PUBLISHED 1
 int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
                          const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
-                         const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status);
+                         const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status, int form);
 
 /* Fixed-size detection records for collecting the results of a sharded batch (new functionality: the reference's
  * inference is single-GPU, detect.py:18): slot (image, rank) -> 32 fp32 =

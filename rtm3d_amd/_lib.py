@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_GROUPS, MAX_TAPS = 4, 80
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -81,6 +81,7 @@ SIGNATURES = {
     'rtm3d_forward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
     'rtm3d_ctx_set_graph': (c_int, [c_void_p, c_int]),
     'rtm3d_ctx_debug_memset_in_replay': (c_int, [c_void_p, c_int]),
+    'rtm3d_ctx_debug_read_words': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'rtm3d_ctx_graph_stats': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]),
     'rtm3d_op_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_char_p)]),
@@ -113,7 +114,7 @@ SIGNATURES = {
     'rtm3d_verify_softmax_fuse_f32': (c_int, [c_void_p, ctypes.POINTER(VTensor), ctypes.POINTER(VTensor), c_int, ctypes.POINTER(VTensor),
                                               c_int, c_int, c_int, c_int, c_void_p]),
     'rtm3d_decode3d_slots': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
 }
 
 _lib = None

@@ -253,11 +253,22 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         dstf[c][0] = LDS_F16X8(waddr0 + (SLOT) * HALF_ELEMS * 2 + c * 2048);                \
         dstf[c][1] = LDS_F16X8(waddr1 + (SLOT) * HALF_ELEMS * 2 + c * 2048);                \
     }
+// (timing-only switches, never in the product build: -DC256_T_NOVM drops the counted vmcnt wait, -DC256_T_NOX / -DC256_T_NOW
+// skip the pixel / weight staging of the persistent kernel, -DC256_T_WSAME makes every tile stream channel tile 0's weights:
+// results are wrong, the per-op time says what the piece costs)
+#ifdef C256_T_NOVM
+#define SEG_SYNC_N(VM)                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#else
 #define SEG_SYNC_N(VM)                                                                      \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                       \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     __builtin_amdgcn_s_barrier();                                                           \
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #define MMA_N(i, j, wfrag, FIRST, TAILBAR)                                                  \
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                        \
@@ -268,6 +279,60 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                      \
     if (TAILBAR) __builtin_amdgcn_s_barrier();                                              \
     __builtin_amdgcn_sched_barrier(0);
+// Diagnostic build only (-DC256_STAMPS; tools/gpu_c256_stamps.sh): waves 0 and 4 of every workgroup stamp s_memtime behind every
+// wait and barrier of the K loop of the SECOND tile they process (5 stamps per phase: operand reads issued and returned | counted
+// vmcnt wait | barrier | MFMAs issued | tail barrier) and around that tile's epilogue; workgroups 0 and 101 dump theirs behind the
+// ticket counters (rtm3d_ctx_debug_read_words).  A stamp costs ~100 cycles (s_memtime + its wait): read the phases against each
+// other, not as absolute times.  The product build contains none of this.
+//
+// What the round-5 stamps and timing-only builds said about heads.conv_d6 (profiles/r05_c256_*.txt):
+//   * MFMA segments take their 256 cycles; what an interval waits for is the partner wave's LOAD segment (12 / 4 / 8 / 0 operand
+//     reads + DMA issue: ~340 / 220 / 420 / 100 cycles before the change below, the two middle ones inflated by the tap-table
+//     lookup: a scalar load and its wait in front of the DMA) -> the lookup moved a K-tile ahead: d6 3.73 -> 3.58 ms;
+//   * dropping the counted vmcnt wait changes nothing (the DMA has landed by then: latency is not what a phase waits for);
+//   * reads rebalanced to 8 / 0 / 8 / 0 (WB fragments read beside the MFMAs of phase 1, the next K-tile's WA fragments behind those
+//     of phase 4): no change in time - and unsound as built: a half-tile is retired by each wave's OWN counted wait, waves 4-7 run
+//     one barrier behind, so a read must stay two barriers behind the retiring wait (the round-1 rule "retired one phase before its
+//     first ds_read"); it would need the staging order XB(t+1) | XA(t+2) | WA(t+2) | WB(t+2).  Not kept;
+//   * the matrix pipe is 70 % busy at 1.65 GHz under the profiler, against 65 % at 1.71 GHz before: the chip trades the recovered
+//     cycles for clock (power cap), as the microbenchmark predicts (tools/microbench/mfma_rate.hip: the same loop with 64 KB of
+//     LDS-DMA per K-tile from L2 holds 1.69 GHz at 85 % = 1.44 PFLOP/s on random data; without any staging 1.70-1.76).
+#ifdef C256_STAMPS
+#define C256_STAMP_KT 20
+#define C256_STAMP_N 20
+#define STAMP(k) if ((wave & 3) == 0 && stamp_tile == 1 && t < C256_STAMP_KT) { unsigned long long ts_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); if (lane == 0) lds_stamp[wave >> 2][t][k] = ts_; }
+#define TSTAMP(k) if ((wave & 3) == 0 && stamp_tile < 4) { unsigned long long ts_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); if (lane == 0) lds_tstamp[wave >> 2][stamp_tile][k] = ts_; }
+#else
+#define STAMP(k)
+#define TSTAMP(k)
+#endif
+#ifdef C256_STAMPS
+#define SEG_SYNC_S(VM, K0)                                                                  \
+    STAMP((K0) + 0)                                                                         \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                       \
+    STAMP((K0) + 1)                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    __builtin_amdgcn_s_barrier();                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    STAMP((K0) + 2)
+#define MMA_S(i, j, wfrag, FIRST, TAILBAR, K0)                                              \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                        \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                       \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p)                                   \
+                acc[i][j][c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[c][kk], xf[p][kk], acc[i][j][c][p], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    STAMP((K0) + 3)                                                                         \
+    if (TAILBAR) __builtin_amdgcn_s_barrier();                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    STAMP((K0) + 4)
+#else
+#define SEG_SYNC_S(VM, K0) SEG_SYNC_N(VM)
+#define MMA_S(i, j, wfrag, FIRST, TAILBAR, K0) MMA_N(i, j, wfrag, FIRST, TAILBAR)
+#endif
 #define STEP_N(VM, FIRST, LAST)                                                             \
     {                                                                                       \
         const uint32_t bufb = lds_base + (uint32_t)sp * (BUF_ELEMS * 2);                    \
@@ -275,20 +340,27 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         const uint32_t waddr0 = bufb + wrow_b0, waddr1 = bufb + wrow_b1;                    \
         LOAD_X_N(SLOT_XA)                                                                   \
         LOAD_W_N(wa, SLOT_WA)                                                               \
-        stage(SLOT_WB, t + 1, sp ^ 1);                                                      \
-        SEG_SYNC_N(VM)                                                                      \
-        MMA_N(0, 0, wa, FIRST, 1)                                                           \
+        stage(SLOT_WB, t + 1, sp ^ 1, 0);                                                   \
+        SEG_SYNC_S(VM, 0)                                                                   \
+        MMA_S(0, 0, wa, FIRST, 1, 0)                                                        \
         LOAD_W_N(wb, SLOT_WB)                                                               \
-        stage(SLOT_XB, t + 1, sp ^ 1);                                                      \
-        SEG_SYNC_N(VM)                                                                      \
-        MMA_N(0, 1, wb, FIRST, 1)                                                           \
+        stage(SLOT_XB, t + 1, sp ^ 1, koff1);                                               \
+        SEG_SYNC_S(VM, 5)                                                                   \
+        MMA_S(0, 1, wb, FIRST, 1, 5)                                                        \
         LOAD_X_N(SLOT_XB)                                                                   \
-        stage(SLOT_XA, t + 2, sp);                                                          \
-        SEG_SYNC_N(VM)                                                                      \
-        MMA_N(1, 1, wb, FIRST, 1)                                                           \
-        stage(SLOT_WA, t + 2, sp);                                                          \
-        SEG_SYNC_N(VM)                                                                      \
-        MMA_N(1, 0, wa, FIRST, !(LAST))                                                     \
+        stage(SLOT_XA, t + 2, sp, koff2);                                                   \
+        SEG_SYNC_S(VM, 10)                                                                  \
+        MMA_S(1, 1, wb, FIRST, 1, 10)                                                       \
+        /* the lookup for K-tile position t + 3 sits in this, the shortest load segment (no operand reads): its latency ends */ \
+        /* under the segment's own wait, and it is first used two load segments later */      \
+        int kchan3;                                                                         \
+        int kraw3 = koff_parts(t + 3, kchan3);                                              \
+        stage(SLOT_WA, t + 2, sp, 0);                                                       \
+        SEG_SYNC_S(VM, 15)                                                                  \
+        asm volatile("" : "+s"(kraw3));           /* first use of the loaded word: behind the segment's wait */ \
+        const int koff3 = kraw3 + kchan3;                                                   \
+        MMA_S(1, 0, wa, FIRST, !(LAST), 15)                                                 \
+        koff1 = koff2; koff2 = koff3;                                                       \
         sp ^= 1;                                                                            \
     }
 
@@ -298,6 +370,11 @@ template <int RES, int XNT>
 __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS + 4];   // + two ticket words
+#ifdef C256_STAMPS
+    __shared__ unsigned long long lds_stamp[2][C256_STAMP_KT][C256_STAMP_N];
+    __shared__ unsigned long long lds_tstamp[2][4][4];
+    int stamp_tile = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,7 +437,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                 const uint32_t pix = (uint32_t)((n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P);
                 xo[h][i] = pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8);
             }
+#ifdef C256_T_WSAME
+        wb = a.wgt + g.w_off;        // timing-only: every tile streams channel tile 0's weights (L2-resident for sure)
+#else
         wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
+#endif
     };
     bool live_n;
     locate(v, xo_c, wb_c, gi_c, mt_c, nt_c);
@@ -370,13 +451,27 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 
     // stage half-tile `slot` of the K-tile kpos steps into the current tile (kpos >= T: next tile;
     // no next tile: same addresses into the dummy slot so the DMA count per phase stays constant)
-    auto stage = [&](int slot, int kpos, int par) {
+    // channel / tap offset of the pixel operand of K-tile position kpos (current tile, or the next one's when kpos >= T).  Looked up
+    // a K-tile AHEAD, in the load segment of phase 4 - the one without operand reads - (STEP_N: koff3), and carried in SGPRs (koff1 / koff2 = positions t + 1 / t + 2):
+    // the table lives in the kernel arguments, and a scalar load issued inside a load segment puts its latency - and, through the
+    // shared lgkmcnt counter, that of every ds_read issued before it - in front of the segment's DMA (in-kernel stamps, round 5:
+    // +80 ... +120 cycles on the load segments of phases 2 and 3, which the partner wave's 256-cycle MFMA segment then waits for).
+    auto koff_parts = [&](int kpos, int& chan) -> int {      // returns the table entry (a scalar LOAD), chan = the chunk's channel offset
+        const bool in_cur = kpos < T;
+        const int k = in_cur ? kpos : kpos - T;
+        const int tap = k / a.cpt;
+        chan = (k - tap * a.cpt) * 64;
+        return a.g[in_cur ? gi_c : gi_n].tap_off[tap];
+    };
+    auto koff_of = [&](int kpos) -> int { int c; const int r = koff_parts(kpos, c); return r + c; };
+    auto stage = [&](int slot, int kpos, int par, int koff) {
         const bool in_cur = kpos < T;
         const int k = in_cur ? kpos : kpos - T;
         const uint32_t dst0 = lds_base + (uint32_t)((in_cur || live_n) ? par * BUF_ELEMS + slot * HALF_ELEMS : 2 * BUF_ELEMS) * 2u;
         if (slot < 2) {
-            const int tap = k / a.cpt, q = k - tap * a.cpt;
-            const int koff = a.g[in_cur ? gi_c : gi_n].tap_off[tap] + q * 64;
+#ifdef C256_T_NOX
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
@@ -385,6 +480,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                 else DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
             }
         } else {
+#ifdef C256_T_NOW
+            return;
+#endif
             const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -404,8 +502,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     const f16x4 lo4 = {lo, lo, lo, lo};
 
     // ---- prologue (once per workgroup): tile 0 complete, XA(1), WA(1) in flight
-    stage(SLOT_XA, 0, 0); stage(SLOT_WA, 0, 0); stage(SLOT_WB, 0, 0); stage(SLOT_XB, 0, 0);
-    stage(SLOT_XA, 1, 1); stage(SLOT_WA, 1, 1);
+    stage(SLOT_XA, 0, 0, koff_of(0)); stage(SLOT_WA, 0, 0, 0); stage(SLOT_WB, 0, 0, 0); stage(SLOT_XB, 0, 0, koff_of(0));
+    stage(SLOT_XA, 1, 1, koff_of(1)); stage(SLOT_WA, 1, 1, 0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
@@ -413,6 +511,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     f16x8 xf[4][2], wa[2][2], wb[2][2];
     int sp = 0;                                           // LDS buffer of the current K-tile
     int tpar = 0;
+    int koff1 = koff_of(1), koff2 = koff_of(2);           // T >= 4: both inside the first tile
+
     for (;;) {
         // draw the ticket of the tile after next (unless the last draw already came back empty); it is
         // published through LDS after the first K-tile.  Inline asm: were this a returning VMEM op the
@@ -436,6 +536,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 #pragma unroll
                     for (int p = 0; p < 4; ++p) acc[i][j][c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int t = 0;
+        TSTAMP(0)
         STEP_N(24, 1, 0)
         if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(ticket) : : "memory");
@@ -453,6 +554,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         // epilogue, waves 4-7 (one barrier behind) after theirs: otherwise each group would sit at a
         // barrier for the whole of the other group's epilogue (measured: 2 x 2.8 us per tile).
         if (wave < 4) __builtin_amdgcn_s_barrier();
+        TSTAMP(1)
 
         // ---- epilogue of the current tile: no loads, 16 independent 16-byte stores
         {
@@ -512,7 +614,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                     }
             }
         }
+        TSTAMP(2)
         if (wave >= 4) __builtin_amdgcn_s_barrier();
+        TSTAMP(3)
+#ifdef C256_STAMPS
+        ++stamp_tile;
+#endif
         if (!live_n) break;
         vnext = __builtin_amdgcn_readfirstlane(lds_ticket[tpar]);
         tpar ^= 1;
@@ -520,6 +627,15 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         wb_c = wb_n; gi_c = gi_n; mt_c = mt_n; nt_c = nt_n;
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
+#ifdef C256_STAMPS
+    if ((blockIdx.x == 0 || blockIdx.x == 101) && (wave & 3) == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        unsigned long long* dst = (unsigned long long*)(tile_ctr + 1024) + (blockIdx.x ? 1 : 0) * 1024 + (wave >> 2) * 512;
+        for (int i = lane; i < C256_STAMP_KT * C256_STAMP_N; i += 64) dst[i] = (&lds_stamp[wave >> 2][0][0])[i];
+        if (lane < 16) dst[C256_STAMP_KT * C256_STAMP_N + lane] = (&lds_tstamp[wave >> 2][0][0])[lane];
+        if (lane == 16) dst[C256_STAMP_KT * C256_STAMP_N + 16] = (unsigned long long)T;
+    }
+#endif
 }
 
 struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
@@ -554,6 +670,9 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
     nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
     if (a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
         HaloTaps ht;
+#ifdef C256_T_NOHALO9
+        if (a.ntaps == 9) {} else          // (same-box A/B only: 3x3 layers on the generic persistent form)
+#endif
         if (!a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
             return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, stat_out, s);
         if (stat_out) return hipErrorInvalidValue;   // only the halo kernel writes softmax partials

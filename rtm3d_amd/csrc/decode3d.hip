@@ -4,9 +4,11 @@
 // Replaces optim_decode_bbox3d (utils/model_utils.py:264-312) + scipy L-BFGS-B.
 // The work is latency-bound fp64 (a few hundred kFLOP per object, <= topk objects per image), so the
 // kernel only needs enough lanes in flight: 64-lane workgroups, objects spread over the CUs.
+#include <type_traits>
 #include "common.h"
 #include "lbfgsb.h"
 #include "lbfgsb_wave.h"
+#include "lbfgsb_wave_pub.h"
 #include "../../include/rtm3d_hip.h"
 
 // slot mode (n_per_image != nullptr): object i lives in slot (image = i / topk, rank = i % topk) of
@@ -54,7 +56,10 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 #ifndef D3_WPB_DEFAULT
 #define D3_WPB_DEFAULT 8
 #endif
-template <int D3_WPB>
+// FORM 0: the direct form (two-loop search direction, lbfgsb_wave.h) - the default of the product path;
+// FORM 1: the published subspace step (lbfgsb_wave_pub.h: what SciPy runs), selectable on the product path since round 5
+// (rtm3d_decode3d_slots form = 1): 8.4 KB of LDS per object, i.e. 67 KB per workgroup of eight.
+template <int D3_WPB, int FORM>
 __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
                                                            const double* __restrict__ dim_ref, int ncls,
@@ -62,14 +67,16 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
                                                            double* __restrict__ f_out, int32_t* __restrict__ nit,
                                                            int32_t* __restrict__ status,
                                                            const int32_t* __restrict__ n_per_image, int topk) {
-    __shared__ LbWaveMem mems[D3_WPB];
+    using Mem = typename std::conditional<FORM == 1, lbw_pub::LbWaveMem, LbWaveMem>::type;
+    using KK = typename std::conditional<FORM == 1, lbw_pub::LbWaveK, LbWaveK>::type;
+    __shared__ Mem mems[D3_WPB];
     // These waves are latency chains that issue an instruction every few hundred cycles; beside the MFMA / DMA
     // waves of the next batch's convolutions they lose every arbitration at equal priority and the kernel stretches
     // from 1.3 ms to ~5 ms, into the persistent conv kernels that need whole CUs.  Highest wave priority: the
     // chains run at their own pace, the co-resident conv waves give up a few issue slots.
     __builtin_amdgcn_s_setprio(3);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    LbWaveMem& mem = mems[wave];
+    Mem& mem = mems[wave];
     const int i = blockIdx.x * D3_WPB + wave;
     if (i >= N) return;
     int ki = i;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
         ki = i / topk;
         if (i - ki * topk >= n_per_image[ki]) { if (lane == 0) status[i] = -1; return; }
     }
-    LbWaveK Kk;
+    KK Kk;
     Kk.k00 = K[ki * 9 + 0]; Kk.k02 = K[ki * 9 + 2]; Kk.k11 = K[ki * 9 + 4]; Kk.k12 = K[ki * 9 + 5];
     int c = (int)cls[i];
     c = c < 0 ? 0 : (c >= ncls ? ncls - 1 : c);
@@ -90,7 +97,9 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
     WSYNC();
     double f;
     int it;
-    const int st = lbw_minimize(&mem, Kk, &f, &it, lane, 15000, 15000);
+    int st;
+    if constexpr (FORM == 1) st = lbw_pub::lbw_minimize(&mem, Kk, &f, &it, lane, 15000, 15000);
+    else st = lbw_minimize(&mem, Kk, &f, &it, lane, 15000, 15000);
     WSYNC();
     if (lane < 8) x_out[(size_t)i * 8 + lane] = mem.x[lane];
     if (lane == 0) { f_out[i] = f; nit[i] = it; status[i] = st; }
@@ -98,8 +107,10 @@ __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const
 
 extern void rt_set_error(const char* fmt, ...);
 
-#define D3_LAUNCH(...) hipLaunchKernelGGL(decode3d_wave_kernel<D3_WPB_DEFAULT>, dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
+#define D3_LAUNCH(...) hipLaunchKernelGGL((decode3d_wave_kernel<D3_WPB_DEFAULT, 0>), dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
                                           dim3(64 * D3_WPB_DEFAULT), 0, (hipStream_t)stream, __VA_ARGS__)
+#define D3_LAUNCH_PUB(...) hipLaunchKernelGGL((decode3d_wave_kernel<D3_WPB_DEFAULT, 1>), dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
+                                              dim3(64 * D3_WPB_DEFAULT), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                               const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
@@ -118,13 +129,15 @@ extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const f
 extern "C" int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
                                     const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
                                     const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit,
-                                    int32_t* d_status) {
+                                    int32_t* d_status, int form) {
     if (B <= 0 || topk <= 0 || ncls <= 0) { rt_set_error("decode3d_slots: bad sizes"); return 1; }
+    if (form != RTM3D_SOLVER_DIRECT && form != RTM3D_SOLVER_PUBLISHED) { rt_set_error("decode3d_slots: unknown solver form %d (0 = direct two-loop direction, 1 = published subspace step)", form); return 1; }
     if (!d_n || !d_cls || !d_verts || !d_K_per_image || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
         rt_set_error("decode3d_slots: null pointer"); return 1;
     }
     const int N = B * topk;
-    D3_LAUNCH(N, d_cls, d_verts, d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
+    if (form == RTM3D_SOLVER_PUBLISHED) D3_LAUNCH_PUB(N, d_cls, d_verts, d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
+    else D3_LAUNCH(N, d_cls, d_verts, d_K_per_image, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, d_n, topk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d_slots launch: %s", hipGetErrorString(e)); return 1; }
     return 0;

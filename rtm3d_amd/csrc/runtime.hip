@@ -84,11 +84,13 @@ static const int PROBE_RING = 64;
 static const int TICKET_SLOTS = 56;
 static const int SPLIT_CTRS = 256;       // per-tile arrival counters of the split-K convolutions (self-resetting, shared by all ops)
 static const size_t TILE_CTR_WORDS = 8 + TICKET_SLOTS + SPLIT_CTRS;
+static const size_t DEBUG_WORD0 = 1024;           // diagnostic builds (-DC256_STAMPS) dump in-kernel stamps behind the counters
+static const size_t DEBUG_WORDS = 8192;
 
 static int ensure_tile_ctr(rtm3d_ctx* ctx) {
     if (ctx->tile_ctr) return 0;
-    RT_HIP(hipMalloc((void**)&ctx->tile_ctr, TILE_CTR_WORDS * sizeof(unsigned int)));
-    RT_HIP(hipMemset(ctx->tile_ctr, 0, TILE_CTR_WORDS * sizeof(unsigned int)));
+    RT_HIP(hipMalloc((void**)&ctx->tile_ctr, (DEBUG_WORD0 + DEBUG_WORDS) * sizeof(unsigned int)));
+    RT_HIP(hipMemset(ctx->tile_ctr, 0, (DEBUG_WORD0 + DEBUG_WORDS) * sizeof(unsigned int)));
     ctx->extra.push_back(ctx->tile_ctr);
     return 0;
 }
@@ -926,6 +928,14 @@ extern "C" int rtm3d_ctx_debug_memset_in_replay(rtm3d_ctx* ctx, int enable) {
     if (!ctx) RT_FAIL("ctx_debug_memset_in_replay: null context");
     if (ensure_tile_ctr(ctx)) return 1;
     ctx->test_memset_in_replay = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int rtm3d_ctx_debug_read_words(rtm3d_ctx* ctx, int offset, int n, unsigned int* h_out) {
+    if (!ctx || !h_out || offset < 0 || n < 1 || (size_t)offset + (size_t)n > DEBUG_WORDS) RT_FAIL("ctx_debug_read_words: bad arguments");
+    if (ensure_tile_ctr(ctx)) return 1;
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(h_out, ctx->tile_ctr + DEBUG_WORD0 + offset, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -57,6 +57,15 @@ class Model(object):
         parse_backbone(self._backbone_name)
         if int(config.MODEL.OUT_CHANNELS) != 256 or int(config.MODEL.HEADER_NUM_CONV) != 2:
             raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256, HEADER_NUM_CONV=2')
+        # MODEL.KFNs names the backbone outputs the neck fuses (models/nets/keypoint_fpn_fusion.py:11-17).  The plan is built for
+        # the four outputs every shipped config names; anything else is refused HERE instead of being silently ignored.  (The
+        # reference itself only runs with all four, in order: its backbones always return four maps and KeypointFPNFusion._fpn
+        # asserts len(x) == len(KFNs), keypoint_fpn_fusion.py:36.)
+        want = ['layer1', 'layer2', 'layer3', 'layer4'] if 'RESNET' in self._backbone_name.upper() else ['level2', 'level3', 'level4', 'level5']
+        kfns = config.MODEL.get('KFNs', None) if hasattr(config.MODEL, 'get') else getattr(config.MODEL, 'KFNs', None)
+        if kfns is not None and [str(k) for k in kfns] != want:
+            raise NotImplementedError('MODEL.KFNs = %r: the HIP plan fuses exactly the four backbone outputs %r of %s '
+                                      '(other subsets / orders are not built)' % (list(kfns), want, self._backbone_name))
         # 'rtm3d' (reference main branch) | 'smoke' (head-table variant, SURVEY.md 8 a12: parity unpinned)
         self._head_variant = config.MODEL.get('HEAD_VARIANT', 'rtm3d') if hasattr(config.MODEL, 'get') else getattr(config.MODEL, 'HEAD_VARIANT', 'rtm3d')
         # one heat-map channel per class of cfg.DATASET.OBJs (models/nets/header.py:11)
@@ -420,13 +429,13 @@ class Model(object):
                 'vertex_offset_logits': logits[3]}
 
     # ------------------------------------------------------------------ fused device pipeline
-    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), fp32_verify=False, sparse_heads=False):
+    def detect3d(self, x, K_per_image, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), fp32_verify=False, sparse_heads=False, solver_form=None):
         """forward + 2D decode + 3D decode, all stream-ordered on the device (no host sync).
         K_per_image: (B, 9) float64 CUDA tensor.  Returns (Detections, Boxes3D, logits).
         fp32_verify=True: the network runs in the fp32 verification mode (forward_logits_fp32), the decode kernels are the
         product's own.  sparse_heads=True: the detect.py call surface never reads the dense regression maps, so only the heat
         map is computed densely and the regression branches at the detected peaks (decode2d_sparse); `logits` is then the
-        heat map alone."""
+        heat map alone.  solver_form: 'direct' | 'published' (model_utils.solver_form_id), None = the default."""
         from .model_utils import decode3d_slots, decode_smoke_slots
         if sparse_heads:
             if fp32_verify:
@@ -443,5 +452,5 @@ class Model(object):
         if self._head_variant == 'smoke':
             boxes = decode_smoke_slots(det, logits[1], K_per_image, dim_ref, float(self.config.MODEL.DOWN_SAMPLE))
         else:
-            boxes = decode3d_slots(det, K_per_image, dim_ref, ref_loc)
+            boxes = decode3d_slots(det, K_per_image, dim_ref, ref_loc, form=solver_form)
         return det, boxes, logits

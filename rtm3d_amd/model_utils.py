@@ -49,9 +49,23 @@ class Boxes3D(object):
         return self.x[:, 5:8]
 
 
-def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0), out=None):
-    """Stream-ordered 3D decode of the slots produced by Model.decode2d (no host sync)."""
+SOLVER_FORMS = {'direct': 0, 'published': 1}      # RTM3D_SOLVER_DIRECT / RTM3D_SOLVER_PUBLISHED (include/rtm3d_hip.h)
+DEFAULT_SOLVER_FORM = 'direct'
+
+
+def solver_form_id(form):
+    """'direct' (two-loop search direction: the default, the cheaper one) | 'published' (L-BFGS-B 3.0's subspace step, the
+    arithmetic SciPy runs behind utils/model_utils.py:295-296; +0.16 ms per bs=32 step) | None = DEFAULT_SOLVER_FORM."""
+    form = DEFAULT_SOLVER_FORM if form is None else form
+    if form not in SOLVER_FORMS:
+        raise ValueError('solver form %r: choose one of %s' % (form, sorted(SOLVER_FORMS)))
+    return SOLVER_FORMS[form]
+
+
+def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0), out=None, form=None):
+    """Stream-ordered 3D decode of the slots produced by Model.decode2d (no host sync).  form: see solver_form_id."""
     lib = _lib.load()
+    form_id = solver_form_id(form)
     dev = det.n.device
     B, topk = det.n.shape[0], det.topk
     K = torch.as_tensor(K_per_image, dtype=torch.float64, device=dev).reshape(B, 9).contiguous()
@@ -64,7 +78,7 @@ def decode3d_slots(det, K_per_image, dim_ref, ref_loc=(0.0, -0.5, 20.0), out=Non
         _lib.check(lib.rtm3d_decode3d_slots(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, topk,
                                             det.n.data_ptr(), det.cls.data_ptr(), det.verts.data_ptr(), K.data_ptr(),
                                             dim.data_ptr(), int(dim.shape[0]), loc.data_ptr(), out.x.data_ptr(),
-                                            out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr()), 'decode3d_slots')
+                                            out.fun.data_ptr(), out.nit.data_ptr(), out.status.data_ptr(), form_id), 'decode3d_slots')
     return out
 
 

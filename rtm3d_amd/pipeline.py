@@ -32,11 +32,15 @@ SMALL_BATCH = 2      # batches whose 3D decode (a serial fp64 iteration per obje
 
 class Detect3DPipeline(object):
     def __init__(self, model, batch, device, dim_ref=None, ref_loc=(0.0, -0.5, 20.0), gather=True, depth=None, decode3d=True,
-                 side_cus=0, side_streams=None, sparse_heads=False):
+                 side_cus=0, side_streams=None, sparse_heads=False, solver_form=None):
         self.model, self.B, self.dev = model, batch, torch.device(device)
         # sparse_heads: this call surface hands out detection records, never the dense logits, so the regression branches are
         # evaluated at the detected peaks only (Model.decode2d_sparse); the records agree with the dense path's to fp16 round-off
         self.sparse_heads = bool(sparse_heads)
+        # search direction of the 3D decode: 'direct' | 'published' (model_utils.solver_form_id); checked here, not at the first submit
+        from .model_utils import solver_form_id, DEFAULT_SOLVER_FORM
+        solver_form_id(solver_form)
+        self.solver_form = DEFAULT_SOLVER_FORM if solver_form is None else solver_form
         self.heads = 'peaks' if self.sparse_heads else 'dense' 
         self.topk = int(model.config.DETECTOR.TOPK_CANDIDATES)
         dim_ref = dim_ref if dim_ref is not None else model.config.DETECTOR.dim_ref
@@ -138,7 +142,7 @@ class Detect3DPipeline(object):
         with torch.cuda.stream(side):
             side.wait_event(self.ev_a[s])
             if self.decode3d:
-                decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s])
+                decode3d_slots(self.det[s], K_per_image, self.dim_ref, self.ref_loc, out=self.boxes[s], form=self.solver_form)
             d = self.det[s]
             rec = rdist.pack_records(d.n, d.cls, d.score, d.mproj, d.verts, d.bbox, self.topk,
                                      self.boxes[s] if self.decode3d else None, out=self.rec_local[s])

@@ -152,6 +152,30 @@ def test_no_cpu_fallback():
                 assert 'oracle' not in open(os.path.join(root, f)).read().replace('CPU oracle', ''), f
 
 
+def test_unsupported_config_is_refused_loudly():
+    """Keys the reference reads that the HIP plan is not built for raise at construction, naming the key - none is ignored
+    (MODEL.KFNs: models/nets/keypoint_fpn_fusion.py:11-17; OUT_CHANNELS / HEADER_NUM_CONV: models/nets/header.py:9-13)."""
+    for bb, good in (('DLA-34', ['level2', 'level3', 'level4', 'level5']), ('RESNET-18', ['layer1', 'layer2', 'layer3', 'layer4'])):
+        cfg = rtm3d_amd.kitti_config(bb)
+        assert list(cfg.MODEL.KFNs) == good
+        rtm3d_amd.create_model(cfg)                                    # the shipped lists build
+        for bad in (good[1:], good[::-1], good[:2], ['level3', 'level4', 'level5', 'level6']):
+            c = rtm3d_amd.kitti_config(bb)
+            c.MODEL.KFNs = bad
+            with pytest.raises(NotImplementedError, match='KFNs'):
+                rtm3d_amd.create_model(c)
+    # the DLA list on a ResNet (a yaml that overrides BACKBONE but keeps detault.py's KFNs) is refused too
+    c = rtm3d_amd.kitti_config('DLA-34')
+    c.MODEL.BACKBONE = 'RESNET-18'
+    with pytest.raises(NotImplementedError, match='KFNs'):
+        rtm3d_amd.create_model(c)
+    for key, val in (('OUT_CHANNELS', 128), ('HEADER_NUM_CONV', 3)):
+        c = rtm3d_amd.kitti_config('DLA-34')
+        c.MODEL[key] = val
+        with pytest.raises(NotImplementedError, match='OUT_CHANNELS'):
+            rtm3d_amd.create_model(c)
+
+
 def test_state_dict_surface_and_checkpoint(tmp_path):
     cfg = rtm3d_amd.kitti_config('RESNET-18')
     m = rtm3d_amd.create_model(cfg)

@@ -31,13 +31,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 
 #define LDS_BYTES (128 * 1024)
+// LDS-DMA from inline asm, as rtm3d_amd/csrc/common.h RT_DMA16 (m0 = LDS byte address of the wave's 1 KB run)
+#define DMA16(gptr, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
 
 struct Stamp { unsigned long long c0, r0, c1, r1; };
 
 // MODE 0: registers, 1: LDS re-read, 2: LDS re-read + the conv kernels' barrier schedule.  NX / NW: pixel / channel fragments
 // per wave (k halves 0 and 1 each).  WAVES: waves per workgroup.
 template <int MODE, int NX, int NW, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __restrict__ rnd, float* __restrict__ out, Stamp* __restrict__ stamps, int steps) {
+__global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __restrict__ rnd, float* __restrict__ out, Stamp* __restrict__ stamps, int steps,
+                                                               const f16* __restrict__ dma_w, const f16* __restrict__ dma_x, unsigned x_window) {
     __shared__ __attribute__((aligned(16))) f16 lds[LDS_BYTES / 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __rest
 #pragma unroll
         for (int p = 0; p < NX; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (MODE == 2 && wave >= WAVES / 2) __builtin_amdgcn_s_barrier();       // second half of the waves one barrier behind
+    if (MODE >= 2 && wave >= WAVES / 2) __builtin_amdgcn_s_barrier();       // second half of the waves one barrier behind
+    unsigned xpos = 0;
 
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t bufb = lds_base;
@@ -89,15 +94,24 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __rest
             f16x8 xa[4][2], wa[2][2], wb[2][2];
 #define RD_X(dst, half) _Pragma("unroll") for (int p = 0; p < 4; ++p) { dst[p][0] = LDS_F16X8(bufb + xrow0 + ((half) * 4 + p) * 2048); dst[p][1] = LDS_F16X8(bufb + xrow1 + ((half) * 4 + p) * 2048); }
 #define RD_W(dst, half) _Pragma("unroll") for (int c = 0; c < 2; ++c) { dst[c][0] = LDS_F16X8(bufb + wrow0 + ((half) * 2 + c) * 2048); dst[c][1] = LDS_F16X8(bufb + wrow1 + ((half) * 2 + c) * 2048); }
-#define SYNC() if (MODE == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define SYNC() if (MODE >= 2) { if (MODE == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+            // MODE 3: the conv kernels' staging beside it: per phase ONE 16 KB half-tile = two 1 KB LDS-DMA pieces per wave, into the
+            // half-tile slot of the other buffer the real schedule targets; weights (W slots) from a small region every workgroup
+            // shares (L2 hits), pixels (X slots) from the workgroup's own window of `x_window` bytes walked cyclically
+#define STAGE(slot, other) if (MODE == 3) { \
+                const uint32_t dst = lds_base + (((bufb - lds_base) ^ ((other) ? 64 * 1024 : 0)) + (slot) * 16384); \
+                const f16* src = (slot) >= 2 ? dma_w + ((size_t)((s * 2 + (slot) - 2) & 63) * 8192) \
+                                             : dma_x + (size_t)blockIdx.x * (x_window / 2) + (size_t)(xpos % (x_window / 2)); \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) DMA16(src + (i * 512 + tid) * 8, __builtin_amdgcn_readfirstlane(dst + (uint32_t)((i * 512 + wave * 64) * 16))); \
+                if ((slot) < 2) xpos += 8192; }
 #define MM(i, j, wfrag) \
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int p = 0; p < 4; ++p) \
                 acc[(j) * 2 + c][(i) * 4 + p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[c][kk], xa[p][kk], acc[(j) * 2 + c][(i) * 4 + p], 0, 0, 0); \
-            if (MODE == 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-            RD_X(xa, 0) RD_W(wa, 0) SYNC() MM(0, 0, wa)
-            RD_W(wb, 1) SYNC() MM(0, 1, wb)
-            RD_X(xa, 1) SYNC() MM(1, 1, wb)
-            SYNC() MM(1, 0, wa)
+            if (MODE >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+            RD_X(xa, 0) RD_W(wa, 0) STAGE(3, 1) SYNC() MM(0, 0, wa)
+            RD_W(wb, 1) STAGE(1, 1) SYNC() MM(0, 1, wb)
+            RD_X(xa, 1) STAGE(0, 0) SYNC() MM(1, 1, wb)
+            STAGE(2, 0) SYNC() MM(1, 0, wa)
             bufb = lds_base + ((bufb - lds_base) ^ (64 * 1024));
         } else {
             // one wave per SIMD, 128 x 128 wave tile: fragments of the next step are read while this one multiplies
@@ -125,7 +139,8 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __rest
         asm volatile("" : "+s"(bufb));
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (MODE == 2 && wave < WAVES / 2) __builtin_amdgcn_s_barrier();
+    if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE >= 2 && wave < WAVES / 2) __builtin_amdgcn_s_barrier();
 
     float sum = 0.f;
 #pragma unroll
@@ -136,11 +151,11 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __rest
     if (lane == 0) stamps[blockIdx.x * WAVES + wave] = Stamp{c0, r0, c1, r1};
 }
 
-struct Variant { const char* name; int waves; int lds_bytes_per_mfma; void (*launch)(const f16*, float*, Stamp*, int, hipStream_t); };
+struct Variant { const char* name; int waves; int lds_bytes_per_mfma; void (*launch)(const f16*, float*, Stamp*, int, hipStream_t, const f16*, const f16*, unsigned); unsigned x_window; };
 
 template <int MODE, int NX, int NW, int WAVES>
-static void launch(const f16* rnd, float* out, Stamp* st, int steps, hipStream_t s) {
-    hipLaunchKernelGGL((mfma_rate_kernel<MODE, NX, NW, WAVES>), dim3(256), dim3(WAVES * 64), 0, s, rnd, out, st, steps);
+static void launch(const f16* rnd, float* out, Stamp* st, int steps, hipStream_t s, const f16* dw, const f16* dx, unsigned xw) {
+    hipLaunchKernelGGL((mfma_rate_kernel<MODE, NX, NW, WAVES>), dim3(256), dim3(WAVES * 64), 0, s, rnd, out, st, steps, dw, dx, xw);
 }
 
 int main(int argc, char** argv) {
@@ -160,17 +175,24 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_out, (size_t)256 * 512 * 4));
     CK(hipMalloc(&d_st, (size_t)256 * 8 * sizeof(Stamp)));
     CK(hipMemcpy(d_rnd, h.data(), n_rnd * 2, hipMemcpyHostToDevice));
+    // pixel source of the dma_* variants: 256 windows of up to 8 MB (random halves, replicated from the 32 MB image)
+    f16* d_x;
+    CK(hipMalloc(&d_x, (size_t)256 * (8u << 20) + (64 << 10)));
+    for (size_t off = 0; off < (size_t)256 * (8u << 20); off += n_rnd * 2) CK(hipMemcpy((char*)d_x + off, d_rnd, n_rnd * 2, hipMemcpyDeviceToDevice));
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     const Variant vs[] = {
-        {"reg2   (registers, 2 waves/SIMD, 128x64 wave tile)", 8, 0, launch<0, 8, 4, 8>},
-        {"reg1   (registers, 1 wave/SIMD, 128x128 wave tile)", 4, 0, launch<0, 8, 8, 4>},
-        {"lds384 (LDS re-read 384 B/MFMA, 2 waves/SIMD)     ", 8, 384, launch<1, 8, 4, 8>},
-        {"lds256 (LDS re-read 256 B/MFMA, 1 wave/SIMD)      ", 4, 256, launch<1, 8, 8, 4>},
-        {"lds384b(as lds384 + the conv kernels' barriers)    ", 8, 384, launch<2, 8, 4, 8>},
+        {"reg2   (registers, 2 waves/SIMD, 128x64 wave tile)", 8, 0, launch<0, 8, 4, 8>, 0},
+        {"reg1   (registers, 1 wave/SIMD, 128x128 wave tile)", 4, 0, launch<0, 8, 8, 4>, 0},
+        {"lds384 (LDS re-read 384 B/MFMA, 2 waves/SIMD)     ", 8, 384, launch<1, 8, 4, 8>, 0},
+        {"lds256 (LDS re-read 256 B/MFMA, 1 wave/SIMD)      ", 4, 256, launch<1, 8, 8, 4>, 0},
+        {"lds384b(as lds384 + the conv kernels' barriers)    ", 8, 384, launch<2, 8, 4, 8>, 0},
+        {"dma_l2 (lds384b + 64 KB LDS-DMA per K-tile, L2 hits)", 8, 384, launch<3, 8, 4, 8>, 128u << 10},
+        {"dma_mall(same, pixels: 1 MB window per workgroup)   ", 8, 384, launch<3, 8, 4, 8>, 1u << 20},
+        {"dma_hbm (same, pixels: 8 MB window per workgroup)   ", 8, 384, launch<3, 8, 4, 8>, 8u << 20},
     };
     printf("%-54s %9s %9s %9s %9s\n", "variant", "ms/launch", "TFLOP/s", "clock GHz", "pipe busy");
     for (const Variant& v : vs) {
@@ -182,14 +204,14 @@ int main(int argc, char** argv) {
         const auto t0 = std::chrono::steady_clock::now();
         int warm = 0;
         for (;;) {
-            for (int i = 0; i < 20; ++i) v.launch(d_rnd, d_out, d_st, steps, s);
+            for (int i = 0; i < 20; ++i) v.launch(d_rnd, d_out, d_st, steps, s, d_rnd, d_x, v.x_window);
             warm += 20;
             CK(hipStreamSynchronize(s));
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= warm_s) break;
         }
         const int timed = 60;
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < timed; ++i) v.launch(d_rnd, d_out, d_st, steps, s);
+        for (int i = 0; i < timed; ++i) v.launch(d_rnd, d_out, d_st, steps, s, d_rnd, d_x, v.x_window);
         CK(hipEventRecord(e1, s));
         CK(hipEventSynchronize(e1));
         CK(hipGetLastError());
