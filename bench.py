@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument('--no-sparse-probe', action='store_true', help='skip the informational detect_surface_sparse_heads block (a few pipelined steps of the peaks-only mode after the timed region)')
     ap.add_argument('--sparse-heads', action='store_true', help='DIAGNOSTIC (not the BASELINE line): the detect3d call surface with the regression head branches evaluated at the detected peaks only (Model.decode2d_sparse); Model.forward() and the headline keep all four dense maps')
     ap.add_argument('--zero-weights', action='store_true', help='DIAGNOSTIC: all weights and biases zero (every activation is 0): what the same kernels do when the MFMA operands carry no energy (profiles/r03_heads_clock.txt)')
+    ap.add_argument('--solver-form', choices=['direct', 'published'], default=None,
+                    help="search direction of the 3D decode inside the timed step (rtm3d_decode3d_slots form): 'direct' = two-loop recursion, "
+                         "'published' = L-BFGS-B 3.0's subspace step, the arithmetic SciPy runs for the reference; default: rtm3d_amd.model_utils.DEFAULT_SOLVER_FORM")
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
     ap.add_argument('--rehearse-one-gpu', action='store_true', help='DIAGNOSTIC: the N ranks of --gpus N all run on GPU 0 and exchange their records over gloo through host memory (RCCL refuses duplicate devices): the whole N > 1 code path - shards, pipelined gather, ordering, diagnostics - on a one-GPU box; the line is marked INVALID')
@@ -226,7 +229,23 @@ def _box_stats(boxd):
     return out
 
 
-def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2):
+def csrc_sha1():
+    """sha1 over the kernel sources (rtm3d_amd/csrc/*.hip, *.h, Makefile): what a committed PMC profile is 'of'."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'rtm3d_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')) or f == 'Makefile':
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()
+
+
+def _default_solver_form():
+    from rtm3d_amd.model_utils import DEFAULT_SOLVER_FORM
+    return DEFAULT_SOLVER_FORM
+
+
+def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2, solver_form=None):
     """BASELINE metric, second half: 3D-box L-inf of the device pipeline vs the CPU reference path (the oracle), on
     the first k images of the benchmark workload (`x_dev` = the benchmark batch: the device runs the SAME plan / kernels
     as the timed steps on the whole batch, the oracle the first k images of it).  Regimes:
@@ -242,8 +261,12 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2):
               itself moves for an input error of that size (the yardstick for the two e2e distributions)."""
     from oracle import rtm3d_ref, decode3d_ref
     from rtm3d_amd import weights
-    from rtm3d_amd.model_utils import decode3d_slots
+    from rtm3d_amd.model_utils import decode3d_slots as _decode3d_slots, DEFAULT_SOLVER_FORM
     from tests.golden.cases import plant_cuboids
+    solver_form = DEFAULT_SOLVER_FORM if solver_form is None else solver_form
+
+    def decode3d_slots(det_, K_, dim_, loc_):          # every decode of this block runs the form the timed step ran
+        return _decode3d_slots(det_, K_, dim_, loc_, form=solver_form)
     t_start = time.perf_counter()
     th, tk = float(cfg.DETECTOR.SCORE_THRESH), int(cfg.DETECTOR.TOPK_CANDIDATES)
     dim_ref = cfg.DETECTOR.dim_ref
@@ -311,9 +334,10 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2):
             st_boxd.extend(list(dv))
             st['box_linf'] = max(st['box_linf'], float(dv.max()))
     st['boxes'] = _box_stats(st_boxd)
-    # the same stage inputs through the solver's PUBLISHED form (L-BFGS-B's subspace step, the form SciPy runs; kept as a
-    # cross-check kernel): tells an implementation difference of the product's direct two-loop form from an object on which any
-    # two correct implementations stop an iteration apart
+    st['solver_form'] = solver_form                # the form of rtm3d_decode3d_slots the timed step (and this block) ran
+    # the same stage inputs through the solver's PUBLISHED form (L-BFGS-B's subspace step, the form SciPy runs; one lane per
+    # object: the flat cross-check entry): tells an implementation difference of the direct two-loop form from an object on
+    # which any two correct implementations stop an iteration apart
     from rtm3d_amd.model_utils import solve_boxes
     pub_boxd, pub_nit = [], 0
     for b in range(k):
@@ -629,7 +653,8 @@ def main():
 
     from rtm3d_amd.pipeline import Detect3DPipeline
     pipe = Detect3DPipeline(model, B, dev, gather='always' if use_dist else True, decode3d=not args.diag_no_decode3d, side_cus=args.side_cus,
-                            depth=args.depth or None, side_streams=args.side_streams or None, sparse_heads=args.sparse_heads) if not args.serial else None
+                            depth=args.depth or None, side_streams=args.side_streams or None, sparse_heads=args.sparse_heads,
+                            solver_form=args.solver_form) if not args.serial else None
     if pipe is not None and use_dist:
         pipe.time_gather = True                 # event pair around the collective on the side stream (diagnostics)
 
@@ -655,7 +680,7 @@ def main():
         if pipe is not None:                        # two-stream pipeline: decode3d(i) overlaps forward(i+1)
             i = pipe.submit(x, K)
             return i, pipe.det[i % pipe.depth]
-        det, boxes, _ = model.detect3d(x, K, sparse_heads=args.sparse_heads)
+        det, boxes, _ = model.detect3d(x, K, sparse_heads=args.sparse_heads, solver_form=args.solver_form)
         rec = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, topk, boxes)
         return rdist.all_gather_records(rec, always=use_dist), det
 
@@ -715,14 +740,22 @@ def main():
         d = info[dom]
         # HBM-side traffic of the dominant kernel: PMC counters cannot be collected live inside a timed
         # run, so the per-launch figure comes from the committed rocprofv3 --pmc profile of this workload
-        traffic, traffic_src = None, None
-        for prof in ('r04_pmc_heads.json', 'r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
+        # (the file says when and on which tree it was collected: a stale figure shows in the line - `traffic_source`,
+        # `traffic_age_days`, and `traffic_tree` against `tree` = the kernels' source hash of THIS run)
+        traffic, traffic_src, traffic_age, traffic_tree = None, None, None, None
+        for prof in ('r05_pmc_heads.json', 'r04_pmc_heads.json', 'r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', prof)) as f:
                     pmc = json.load(f)
                 if B == 32 and (H, W) == (384, 1280) and d['name'] in pmc['kernels']:
                     traffic = pmc['kernels'][d['name']]['hbm_bytes_corrected'] / 1e9
-                    traffic_src = 'profiles/%s (GB per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024)' % prof
+                    traffic_tree = pmc.get('csrc_sha1')
+                    when = pmc.get('collected_utc')
+                    if when:
+                        import datetime
+                        traffic_age = round((datetime.datetime.utcnow() - datetime.datetime.strptime(when[:19], '%Y-%m-%dT%H:%M:%S')).total_seconds() / 86400.0, 2)
+                    traffic_src = 'profiles/%s (GB per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024; collected %s, commit %s, kernel sources %s)' % (
+                        prof, when or 'at an unrecorded time (file predates round 5)', pmc.get('commit', 'unrecorded'), (traffic_tree or 'unrecorded')[:12])
                     break
             except (OSError, KeyError, ValueError):
                 pass
@@ -730,7 +763,9 @@ def main():
                 'achieved': d['flops'] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
                 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': (d['flops'] / (dom_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS) if dom_ms > 0 else None,
-                'traffic': traffic, 'traffic_source': traffic_src, 'launch_ms': dom_ms, 'launches_timed': dom_n,
+                'traffic': traffic, 'traffic_source': traffic_src, 'traffic_age_days': traffic_age,
+                'traffic_is_of_this_tree': (traffic_tree == csrc_sha1()) if traffic_tree else None,
+                'launch_ms': dom_ms, 'launches_timed': dom_n,
                 'flops_per_launch': d['flops'],
                 'whole_forward_frac': flops_fwd / (sum(i['ms'] for i in info) * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
         # north_star's target is quoted on the backbone alone: its ops' algorithmic FLOPs over their hipEvent times (per-op pass)
@@ -762,7 +797,8 @@ def main():
                'config': {'workload': 'rtm3d_%s_kitti forward+decode2d+decode3d, bs=%d/GPU, %dx%d, fp16 storage fp32 accumulate'
                                       % (bb.lower().replace('-', ''), B, H, W),
                           'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                          'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9},
+                          'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9,
+                          'solver_form': args.solver_form or _default_solver_form()},
                'roofline': roof, 'multi_gpu': multi}
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'
@@ -803,7 +839,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         if not args.no_parity and world == 1 and not args.from_uint8 and not args.sparse_heads:
-            out['parity'] = parity_check(model, cfg, sd, bb, x, args.parity_images, dev)
+            out['parity'] = parity_check(model, cfg, sd, bb, x, args.parity_images, dev, solver_form=args.solver_form)
         else:
             out['parity'] = None
         if (not args.no_sparse_probe and world == 1 and pipe is not None and not args.sparse_heads and not args.from_uint8

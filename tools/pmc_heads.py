@@ -21,6 +21,18 @@ out = {'source': 'rocprofv3 --pmc, 3 separate passes (FETCH_SIZE | WRITE_SIZE GR
                  'dispatches of %s attributed to ops by order within a forward (%s)' % (' / '.join(KERNEL), ', '.join(ops)),
        'correction': 'traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024: gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM)',
        'kernels': {}}
+# provenance (round 5): when and on which kernel sources the passes ran (provenance.json, written on the GPU box by the profiling
+# script beside the pass directories) and the commit this summary was made on: bench.py prints them in `roofline.traffic_source`
+import os, subprocess
+for d in dirs:
+    for cand in (os.path.join(d, 'provenance.json'), os.path.join(os.path.dirname(d.rstrip('/')), 'provenance.json')):
+        if os.path.exists(cand):
+            out.update(json.load(open(cand)))
+            break
+try:
+    out['commit'] = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=os.path.dirname(os.path.abspath(__file__)), text=True).strip()
+except Exception:
+    pass
 for op in ops:
     k = {c: sum(v) / len(v) for c, v in vals[op].items()}
     if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
