@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument('--solver-form', choices=['direct', 'published'], default=None,
                     help="search direction of the 3D decode inside the timed step (rtm3d_decode3d_slots form): 'direct' = two-loop recursion, "
                          "'published' = L-BFGS-B 3.0's subspace step, the arithmetic SciPy runs for the reference; default: rtm3d_amd.model_utils.DEFAULT_SOLVER_FORM")
+    ap.add_argument('--shared-weight-cache', action='store_true', help='N > 1: rank 0 folds and packs the weights and writes the on-disk weight cache, the other ranks build their plans from that file behind a barrier (off by default: measured SLOWER at 4 ranks on a 16-core host share, 3.3 s against 2.8 s from spawn to the first timed step - packing is 0.5 s per rank and the barrier serialises it; for hosts with few cores per rank)')
     ap.add_argument('--per-op', action='store_true', help='also print a per-kernel table to stderr')
     ap.add_argument('--force-launch', action='store_true', help='go through the rank launcher even for --gpus 1 (rehearses the N > 1 path: process group, RCCL all-gather)')
     ap.add_argument('--rehearse-one-gpu', action='store_true', help='DIAGNOSTIC: the N ranks of --gpus N all run on GPU 0 and exchange their records over gloo through host memory (RCCL refuses duplicate devices): the whole N > 1 code path - shards, pipelined gather, ordering, diagnostics - on a one-GPU box; the line is marked INVALID')
@@ -646,6 +647,24 @@ def main():
     model.load_state_dict(sd)
     if args.graph:
         model.use_graph = True
+    wcache_note = None
+    if use_dist and world > 1 and args.shared_weight_cache:
+        # Every rank loads the same state dict; folding BatchNorm, composing the neck's 1x1 pairs and packing 30 M weights is
+        # ~1.5 s of numpy per rank on the rank's share of the host cores (usable // world threads).  Rank 0 does it once and
+        # writes the on-disk weight cache (rtm3d_amd/weight_cache.py, keyed by a digest of the state dict and of the packers);
+        # the other ranks build their plans from that file behind a barrier.
+        import tempfile
+        wdir = os.environ.get('RTM3D_WEIGHT_CACHE_DIR') or os.path.join(tempfile.gettempdir(), 'rtm3d_wcache_%s_%s' % (
+            os.environ.get('MASTER_PORT', '0'), os.environ.get('RTM3D_BENCH_SPAWN_T', '0').replace('.', '_')))
+        os.environ['RTM3D_WEIGHT_CACHE_DIR'] = wdir
+        t_w = time.perf_counter()
+        if rank == 0:
+            model._plan_for(B, H, W, dev, 'peaks' if args.sparse_heads else 'dense')      # packs and saves
+        dist.barrier()
+        if rank != 0:
+            model._plan_for(B, H, W, dev, 'peaks' if args.sparse_heads else 'dense')      # reads rank 0's file
+        wc = model._wcache
+        wcache_note = {'dir': wdir, 'rank': rank, 'hits': wc.hits, 'misses': wc.misses, 'plan_build_s': round(time.perf_counter() - t_w, 2)}
     # this rank's shard of the global synthetic batch (image b uses seed 1234+b: rank independent)
     x = weights.synth_images(B, H, W, seed=1234, first=rank * B).to(dev)
     K = torch.as_tensor(np.tile(weights.synth_intrinsics(), (B, 1)), dtype=torch.float64, device=dev)
@@ -732,6 +751,11 @@ def main():
         local = pipe.rec_local[last_step % pipe.depth] if pipe is not None else rec[rank * B:(rank + 1) * B]
         dt, multi = multi_diagnostics(world, B, args.steps, dt, rec, local, dev, pipe.gather_us(last_step) if pipe is not None else None,
                                       _startup_s(t0))
+        if wcache_note is not None:
+            notes = [None] * world
+            dist.all_gather_object(notes, wcache_note)
+            multi['shared_weight_cache'] = {'dir': wcache_note['dir'], 'per_rank': [{k: n[k] for k in ('rank', 'hits', 'misses', 'plan_build_s')} for n in notes],
+                                            'note': 'rank 0 folds + packs (misses) and writes the file, ranks >= 1 build their plan from it (hits) behind a barrier'}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -800,6 +824,12 @@ def main():
                           'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9,
                           'solver_form': args.solver_form or _default_solver_form()},
                'roofline': roof, 'multi_gpu': multi}
+        # the plan-level A/B switches this process ran with (environment, read once at import: rtm3d_amd/plan.py); all True = the product
+        from rtm3d_amd import plan as _p
+        out['config']['plan_switches'] = {'FOLD_PROJECT_C128': _p.FOLD_PROJECT_C128, 'FOLD_NECK_UP': _p.FOLD_NECK_UP, 'USE_CONV64S2': _p.USE_CONV64S2,
+                                          'S2D_ONLY': _p.S2D_ONLY, 'USE_CONV128': _p.USE_CONV128}
+        if not all(out['config']['plan_switches'].values()):
+            out['DIAGNOSTIC_plan_switches'] = 'a plan-level A/B switch is off: not the product configuration'
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'
         if args.v2_min_tiles is not None:

@@ -90,13 +90,13 @@ typedef struct rtm3d_conv_desc {
     int out_oy[RTM3D_MAX_GROUPS], out_ox[RTM3D_MAX_GROUPS];
     int tap_dy[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS], tap_dx[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS];
     int tap_dc[RTM3D_MAX_GROUPS][RTM3D_MAX_TAPS]; /* channel offset of the tap relative to in_coff (multiple of 8; kernels 0 and 2 only) */
-    int s2d_tensor, s2d_coff;              /* s2d_tensor >= 0 (kernel 0, groups 1, out_scale 1, even output height / width): the output is
+    int s2d_tensor, s2d_coff;              /* s2d_tensor = tensor id + 1, 0 = none (ABI 8; like out_nchw_f32, so that a zero-initialised descriptor asks
+                                              for nothing).  Set (kernel 0 or 5, groups 1, out_scale 1, even output height / width): the output is
                                               written a SECOND time in space-to-depth layout - pixel (y, x) to pixel (y >> 1, x >> 1), channels
                                               s2d_coff + ((y & 1) * 2 + (x & 1)) * cout + c of the half-resolution s2d_tensor - so that the neck
                                               can read the feature map from the grid of its transposed conv's input (plan.py: _neck_up_folds).
                                               With out_tensor < 0 (kernel 0) ONLY this copy is written: its readers are rtm3d_op_maxpool_s2d, a
-                                              stride-2 conv restated on the copy (stride-1 taps with tap_dc, or kernel 7 with in_s2d) and tap_dc taps.
-                                              NOTE for callers that zero-initialise the struct: 0 is a valid tensor id, set -1 for "none". */
+                                              stride-2 conv restated on the copy (stride-1 taps with tap_dc, or kernel 7 with in_s2d) and tap_dc taps. */
     int in_s2d;                            /* kernel 7 only: in_tensor holds the SPACE-TO-DEPTH copy (half resolution, 4 x cin channels at in_coff) of the
                                               map the conv is stated on (Hm, Wm, taps, stride as for the ordinary map) */
     int relu;
@@ -144,7 +144,7 @@ int rtm3d_op_conv32s2_fused(rtm3d_ctx* ctx, int in_tensor, int in_coff, int conv
  * with lane = fk * 16 + row, element j = root weight [tile * 16 + row][s * 32 + (j >> 2) * 16 + fk * 4 + (j & 3)] over the
  * concatenated input [x2 | x1] (the K order in which the conv's accumulator fragments are handed to the root's MFMAs);
  * fp32 biases [64] with BN folded.  Same result as the rtm3d_op_conv / rtm3d_op_maxpool launches it replaces up to fp32
- * summation order.  out_tensor < 0: the ordinary copy of `out` is not written (needs s2d_tensor).  s2d_tensor >= 0: `out` is written a second time in space-to-depth layout - pixel (y, x) to half-resolution
+ * summation order.  out_tensor < 0: the ordinary copy of `out` is not written (needs s2d_tensor).  s2d_tensor >= 0 (a plain tensor id here, -1 = none): `out` is written a second time in space-to-depth layout - pixel (y, x) to half-resolution
  * pixel (y >> 1, x >> 1), channels s2d_coff + ((y & 1) * 2 + (x & 1)) * 64 + c of s2d_tensor - which lets the neck read the
  * feature map at the resolution of the transposed conv's INPUT grid (rtm3d_amd/plan.py: RealizedPlan._neck_up_folds).        */
 int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, int res_tensor, int res_coff, int conv_relu,

@@ -224,8 +224,11 @@ static void* get_blob(rtm3d_ctx* ctx, int id, size_t* bytes) {
 extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     if (!ctx || !d) RT_FAIL("op_conv: null argument");
     Tensor* in = get_tensor(ctx, d->in_tensor);
-    // (out_tensor < 0 together with s2d_tensor >= 0: only the space-to-depth copy of the output is written)
-    const bool s2d_only = !d->out_nchw_f32 && d->out_tensor < 0 && d->s2d_tensor >= 0;
+    // rtm3d_conv_desc.s2d_tensor is tensor id + 1 (0 = none: a zero-initialised descriptor asks for no copy)
+    if (d->s2d_tensor < 0) RT_FAIL("op_conv: s2d_tensor = %d (tensor id + 1, 0 = none)", d->s2d_tensor);
+    const int s2d_id = d->s2d_tensor - 1;
+    // (out_tensor < 0 together with a space-to-depth tensor: only the space-to-depth copy of the output is written)
+    const bool s2d_only = !d->out_nchw_f32 && d->out_tensor < 0 && s2d_id >= 0;
     Tensor* out = (d->out_nchw_f32 || s2d_only) ? nullptr : get_tensor(ctx, d->out_tensor);
     Tensor* res = d->res_tensor >= 0 ? get_tensor(ctx, d->res_tensor) : nullptr;
     if (!in) RT_FAIL("op_conv: bad input tensor %d", d->in_tensor);
@@ -284,9 +287,9 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         a.g[g].in_coff = d->in_coff[g]; a.g[g].out_coff = d->out_coff[g]; a.g[g].res_coff = d->res_coff[g];
         a.g[g].out_oy = d->out_oy[g]; a.g[g].out_ox = d->out_ox[g];
     }
-    if (d->s2d_tensor >= 0) {
-        Tensor* s2 = get_tensor(ctx, d->s2d_tensor);
-        if (!s2 || (!out && !s2d_only)) RT_FAIL("op_conv: bad space-to-depth tensor %d", d->s2d_tensor);
+    if (s2d_id >= 0) {
+        Tensor* s2 = get_tensor(ctx, s2d_id);
+        if (!s2 || (!out && !s2d_only)) RT_FAIL("op_conv: bad space-to-depth tensor %d", s2d_id);
         if (s2d_only && d->kernel != 0) RT_FAIL("op_conv: writing ONLY the space-to-depth copy needs kernel 0");
         if ((d->kernel != 0 && d->kernel != 5) || d->groups != 1 || d->out_scale != 1 || d->out_oy[0] || d->out_ox[0] || (d->Hm & 1) || (d->Wm & 1) || (d->cout % 8))
             RT_FAIL("op_conv: the space-to-depth copy needs kernel 0 or 5, one group, out_scale 1 and an even output height / width");
@@ -304,7 +307,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
     const double M = (double)a.M;
     op.flops = 2.0 * M * d->groups * (double)d->cin * d->ntaps * d->cout;
     op.bytes = 2.0 * M * d->groups * (d->cin + d->cout * (d->out_nchw_f32 ? 2 : 1)) + (res ? 2.0 * M * d->groups * d->cout : 0.0)
-               + (d->s2d_tensor >= 0 && !s2d_only ? 2.0 * M * d->cout : 0.0);
+               + (s2d_id >= 0 && !s2d_only ? 2.0 * M * d->cout : 0.0);
     if (d->kernel == 2) {
         if (d->cin % 64 || d->cout % 256 || d->out_nchw_f32) RT_FAIL("op_conv(mfma256): needs cin %% 64 == 0, cout %% 256 == 0, NHWC output (cin=%d cout=%d)", d->cin, d->cout);
         a.cpt = d->cin / 64; a.ksteps = d->ntaps * a.cpt;
@@ -554,6 +557,11 @@ extern "C" int rtm3d_op_conv64_root(rtm3d_ctx* ctx, int in_tensor, int in_coff, 
     if (pool) {
         if (pool->H * 2 != in->H || pool->W * 2 != in->W || pool->B != in->B || pool_coff < 0 || pool_coff + 64 > pool->C || (pool_coff % 8))
             RT_FAIL("op_conv64_root: pooled output slice mismatch (half resolution, 64 channels)");
+        // the pooled map and the space-to-depth copy are both half resolution and may be slices of ONE tensor: different lanes of
+        // one launch write them, so their channel ranges must not meet
+        if (s2d && pool == s2d && pool_coff < s2d_coff + 256 && s2d_coff < pool_coff + 64)
+            RT_FAIL("op_conv64_root: the pooled slice [%d,%d) overlaps the space-to-depth slice [%d,%d) of the same tensor", pool_coff, pool_coff + 64, s2d_coff, s2d_coff + 256);
+        if (pool == in || pool == res || (out && pool == out)) RT_FAIL("op_conv64_root: the pooled output aliases an operand");
     }
     size_t wc = 0, bc = 0, wr = 0, br = 0;
     const f16* w0 = (const f16*)get_blob(ctx, w_conv_blob, &wc);

@@ -279,7 +279,8 @@ class Model(object):
         written tensor slice and per folded weight array with its largest |value|, the head-room to 65504 and an ``overflow``
         flag, largest first.  ``strict=True`` raises ``OverflowError`` naming the first offending tensor in plan order."""
         self.forward_logits_fp32(x)
-        rows = self._verify[1].range_report()
+        B, _, H, W = x.shape
+        rows = self._verify[1].range_report(realized=self._plan_for(B, H, W, x.device))
         if strict:
             bad = sorted([r for r in rows if r['overflow']], key=lambda r: r['order'])       # the first one in plan order: the cause
             if bad:

@@ -657,12 +657,27 @@ class RealizedPlan(object):
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'] + widen.get(i, 0), t['pad'], ctypes.byref(tid)), 'tensor_create')
             self.tids.append(tid.value)
         self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
+        self.weight_ranges = []                 # per recorded conv: largest |weight| / |bias| as realized (after the level rewrites)
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
         entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
         folds = self._project_folds() if FOLD_PROJECT else {}
         skip = set(folds.values()) | {f['up'] for f in nfold}
         s2d_of = {f['tail']: f for f in nfold if 'tail' in f}   # conv64_root launch -> the fold its second (space-to-depth) output feeds
         neck_by = {f['pj']: f for f in nfold}
+        # output slices of the un-rewritten plan that this realization never writes (for verify.range_report): the `up` maps the
+        # neck fold composes away, the projected residuals, feature maps that exist only as their space-to-depth copy
+        self.unwritten = set()
+        for kk in skip:
+            for o in plan.ops[kk]['out'] if plan.ops[kk]['op'] == 'conv' else []:
+                if o is not None:
+                    self.unwritten.add((o.tid, o.coff, o.C))
+        for kk in getattr(self, '_s2d_only_producers', ()):
+            o = plan.ops[kk]['out'][0]
+            self.unwritten.add((o.tid, o.coff, o.C))
+        for kk, f in s2d_of.items():
+            if f.get('s2d_only'):
+                o = plan.ops[tail[kk][0]]['out'][0]
+                self.unwritten.add((o.tid, o.coff, o.C))
         folded_by = {}
         for c2k, pjk in folds.items():
             folded_by[c2k] = self._folded_conv(plan.ops[c2k], plan.ops[pjk])
@@ -1139,6 +1154,10 @@ class RealizedPlan(object):
         return bid.value
 
     def _op_conv(self, op):
+        # what this recorded conv stores as fp16 (the REALIZED weights: composed neck taps A_up W, summed fold biases ...):
+        # Model.check_range reports them next to the un-rewritten plan's rows (verify.range_report(realized=...))
+        self.weight_ranges.append({'op': op['name'], 'max_abs_w': float(np.abs(op['w']).max()) if np.size(op['w']) else 0.0,
+                                   'max_abs_bias': float(np.abs(op['bias']).max()) if np.size(op['bias']) else 0.0})
         d = _lib.ConvDesc()
         G = op['groups']
         d.in_tensor = self.tids[op['inp'][0].tid]
@@ -1159,13 +1178,20 @@ class RealizedPlan(object):
         d.softmax_stat_slot = self._stat_slots.get(self._k, -1)
         d.out_nchw_f32 = op['out_nchw']
         d.out_H, d.out_W = op['out_hw']
-        d.s2d_tensor, d.s2d_coff, d.in_s2d = -1, 0, 0
+        d.s2d_tensor, d.s2d_coff, d.in_s2d = 0, 0, 0              # s2d_tensor: tensor id + 1, 0 = none
         M = self.plan.B * op['Hm'] * op['Wm']
         variant = op.get('variant')
-        s2d = getattr(self, '_s2d_for', {}).get(self._k) if 'tap_dc' not in op else None
+        s2d = getattr(self, '_s2d_for', {}).get(self._k)
+        if s2d is not None and 'tap_dc' in op:
+            #  the producer of a space-to-depth copy was itself rewritten with per-tap channel offsets: no kernel with the
+            # second store takes tap_dc, so the copy would silently stay zero and the neck fold behind it would read zeros
+            raise RuntimeError('plan: %s must write a space-to-depth copy of its output but was rewritten with tap_dc (project fold); '
+                               'the two level rewrites exclude each other' % op['name'])
+        if self._k in getattr(self, '_s2d_only_producers', ()) and s2d is None:
+            raise RuntimeError('plan: %s is marked as writing only a space-to-depth copy but no copy was planned for it' % op['name'])
         if s2d is not None:
             # this conv's output feeds a neck up-fold: second copy in space-to-depth layout, 128-pixel kernel (the one whose epilogue has it)
-            d.s2d_tensor, d.s2d_coff = self.tids[s2d[0].tid], s2d[1]
+            d.s2d_tensor, d.s2d_coff = self.tids[s2d[0].tid] + 1, s2d[1]
             variant = 5 if conv64_eligible(op) else 0
             if self._k in getattr(self, '_s2d_only_producers', ()):
                 d.out_tensor = -1                 # every reader takes the copy: the ordinary output is not written
@@ -1173,6 +1199,9 @@ class RealizedPlan(object):
             variant = (5 if conv64_eligible(op) else 7 if conv64s2_eligible(op) and self.plan.B * (op['Hm'] // 4) * (op['Wm'] // 32) >= 64
                        else 6 if USE_CONV128 and conv128_eligible(op, self.plan.B)
                        else choose_variant(op['cin'], op['cout'], M, G, op['out_nchw'], len(op['taps'][0]), op['in_stride']))
+        if self._k in getattr(self, '_in_s2d_for', {}) and variant != 7:
+            #  this conv's input exists ONLY as its space-to-depth copy, which kernel 7 alone can read
+            raise RuntimeError('plan: the input of %s exists only as a space-to-depth copy but the conv went to kernel variant %r' % (op['name'], variant))
         if variant == 7:
             assert conv64s2_eligible(op), op['name']
             d.kernel, d.bn_tile = 7, 128

@@ -182,9 +182,13 @@ class VerifyPlanF32(object):
                     raise AssertionError('VerifyPlanF32: unknown op %r' % kind)
         return tuple(outs)
 
-    def range_report(self):
+    def range_report(self, realized=None):
         """After ``forward``: the largest |value| of every tensor slice an op of the plan writes (fp32 run) and of every folded
-        weight array, against the fp16 range the product path stores them in.  The reference runs in fp32
+        weight array, against the fp16 range the product path stores them in.  realized: the RealizedPlan of the same shape -
+        its level rewrites store weights this executor never sees (the neck fold's composed taps A_up W and bias A_bias + b, the
+        project folds' summed biases): their rows are added as 'weight (realized)' / 'bias (realized)', and activation rows whose
+        tensor the realized plan no longer writes (the neck's `up` maps, maps that exist only as their space-to-depth copy) are
+        tagged 'materialised': False (their values still bound what the fused kernels accumulate in fp32).  The reference runs in fp32
         (models/model.py:20-27) and cannot overflow; the product stores activations and weights as fp16 (max 65504) with no
         clamp: a checkpoint whose activations exceed that yields inf / NaN logits there (which rtm3d_decode2d handles like the
         reference's own NaN / Inf: tests/test_gpu_parity.py).  Rows: {'what': 'activation' | 'weight', 'op', 'tensor', 'max_abs',
@@ -200,7 +204,8 @@ class VerifyPlanF32(object):
             t = P.tensors[s.tid]
             pad = t['pad']
             v = float(self.bufs[s.tid][:, pad:pad + t['H'], pad:pad + t['W'], s.coff:s.coff + s.C].abs().max())
-            rows.append({'what': 'activation', 'order': len(rows), 'op': op_name, 'tensor': names.get((s.tid, s.coff, s.C), 'tensor%d[%d:%d]' % (s.tid, s.coff, s.coff + s.C)),
+            rows.append({'what': 'activation', 'order': len(rows), 'op': op_name, 'slice': (s.tid, s.coff, s.C),
+                         'tensor': names.get((s.tid, s.coff, s.C), 'tensor%d[%d:%d]' % (s.tid, s.coff, s.coff + s.C)),
                          'max_abs': v, 'headroom': FP16_MAX / v if v > 0 else float('inf'), 'overflow': not (v <= FP16_MAX)})
 
         for op in P.ops:
@@ -219,6 +224,16 @@ class VerifyPlanF32(object):
                 act(op['name'], op['out'])
             elif kind == 'softmax':
                 act(op['name'], op['z_out'])
+        if realized is not None:
+            for r in rows:
+                if r['what'] == 'activation':
+                    r['materialised'] = r['slice'] not in realized.unwritten
+            for wr in realized.weight_ranges:
+                for what, key in (('weight (realized)', 'max_abs_w'), ('bias (realized)', 'max_abs_bias')):
+                    v = wr[key]
+                    rows.append({'what': what, 'order': len(rows), 'op': wr['op'], 'tensor': 'as stored by the recorded op', 'max_abs': v,
+                                 'headroom': FP16_MAX / v if v > 0 else float('inf'),
+                                 'overflow': what.startswith('weight') and not (v <= FP16_MAX)})      # biases stay fp32
         rows.sort(key=lambda r: -r['max_abs'] if r['max_abs'] == r['max_abs'] else -float('inf'))
         return rows
 

@@ -575,7 +575,7 @@ def test_round4_entry_points_refuse_bad_arguments():
         # conv descriptor: a tap naming channels outside the tensor; a space-to-depth copy on an odd map / with the wrong kernel
         d = _lib.ConvDesc()
         t_a, t_b = tensor(1, 8, 16, 128, 1), tensor(1, 8, 16, 128, 1)
-        d.in_tensor, d.out_tensor, d.res_tensor, d.s2d_tensor, d.softmax_stat_slot = t_a, t_b, -1, -1, -1
+        d.in_tensor, d.out_tensor, d.res_tensor, d.s2d_tensor, d.softmax_stat_slot = t_a, t_b, -1, 0, -1
         d.Hm, d.Wm, d.in_stride, d.out_scale, d.cin, d.cout, d.groups, d.ntaps = 8, 16, 1, 1, 64, 128, 1, 2
         d.kernel, d.bn_tile = 0, 128
         d.w_blob, d.bias_blob = blob(2 * 128 * 64 * 2), blob(128 * 4)
@@ -585,7 +585,7 @@ def test_round4_entry_points_refuse_bad_arguments():
         assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) != 0 and b'outside' in lib.rtm3d_last_error()
         d.tap_dc[0][1] = 64
         t_half = tensor(1, 4, 8, 512, 0)
-        d.s2d_tensor, d.s2d_coff = t_half, 0
+        d.s2d_tensor, d.s2d_coff = t_half + 1, 0          # tensor id + 1 (0 = none)
         assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) == 0, lib.rtm3d_last_error()
         d.s2d_coff = 8
         assert lib.rtm3d_op_conv(ctx, ctypes.byref(d)) != 0 and b'space-to-depth' in lib.rtm3d_last_error()

@@ -1047,7 +1047,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-one-gpu', '--steps', '3', '--warmup', '1',
                         '--batch', '4', '--height', '128', '--width', '256', '--backbone', 'RESNET-18', '--no-cpu-baseline', '--no-parity',
-                        '--no-sparse-probe'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-sparse-probe', '--shared-weight-cache'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
@@ -1055,6 +1055,11 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
     mg = out['multi_gpu']
     assert out['n_gpus'] == 2 and mg['ranks_seen'] == 2 and mg['gathered_shape'] == [8, 100, 32] and len(mg['per_rank_ms_per_step']) == 2
     assert out['config']['global_batch'] == 8 and 'INVALID' in out
+    # round 5 (--shared-weight-cache): rank 0 folds + packs the weights once and writes the cache file, rank 1 builds its plan
+    # from it (no misses); and the N > 1 line keeps rank 0's roofline block
+    wc = {n['rank']: n for n in mg['shared_weight_cache']['per_rank']}
+    assert wc[0]['misses'] > 0 and wc[1]['misses'] == 0 and wc[1]['hits'] > 0, wc
+    assert out['roofline'] and out['roofline']['launch_ms'] > 0 and out['roofline']['per_stage']['heads']['ms'] > 0
 
 
 def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
@@ -1413,6 +1418,12 @@ def test_fp16_range_report_names_the_overflowing_tensor(dev):
     acts = [r for r in rows if r['what'] == 'activation']
     assert len(acts) >= 40 and not any(r['overflow'] for r in rows)
     assert min(r['headroom'] for r in rows) > 50, rows[0]                 # the synthetic checkpoints sit far inside the range
+    #  the report also covers what the level rewrites store: composed neck taps / summed biases of the recorded ops,
+    # and it says which activation rows the realized plan no longer materialises (the neck's `up` maps, s2d-only features)
+    realized = [r for r in rows if r['what'] == 'weight (realized)']
+    assert any('kfpn_up' in r['op'] and 'kfpn_proj' in r['op'] for r in realized), [r['op'] for r in realized][:8]
+    ghost = [r for r in acts if not r['materialised']]
+    assert ghost and any('kfpn_up' in r['op'] for r in ghost) and any(r['materialised'] for r in acts)
     record_measurement('fp16_range', 'healthy', {'largest': rows[0]['max_abs'], 'tensor': rows[0]['tensor'], 'op': rows[0]['op']})
     m.release_verify()
     sd2 = {k: v.clone() for k, v in sd.items()}
