@@ -718,6 +718,16 @@ def main():
         pk = [t.data_ptr() for t in plan.peak_out] + [0, 0]
         plan.peak.forward_timed(stream, 0, pk)
         peak_info = plan.peak.forward_timed(stream, 0, pk)
+    # wall time of the three stages in the REAL replay (side lanes on: the neck's up-sampling chains overlap its top-down chain,
+    # which the one-op-after-the-other pass above cannot see): events at the stage boundaries, best of five replays
+    stage_wall = None
+    if not args.sparse_heads:
+        nm_ = [i['name'] for i in info]
+        first = lambda pred: next((k for k, n in enumerate(nm_) if pred(n)), None)
+        marks = [first(lambda n: n.startswith('backbone')), first(lambda n: n.startswith(('kfpn', 'fusion'))), first(lambda n: n.startswith('heads'))]
+        if all(m is not None for m in marks) and marks == sorted(marks):
+            runs = [plan.forward_marks(stream, x.data_ptr(), optrs, marks) for _ in range(6)][1:]
+            stage_wall = dict(zip(('backbone', 'neck', 'heads'), [min(r[k] for r in runs) for k in range(3)]))
     dom = max(range(len(info)), key=lambda i: info[i]['ms'])
     if not args.graph:
         plan.probe_set(dom)
@@ -814,6 +824,11 @@ def main():
             stages[nm] = {'ms': round(ms, 4), 'launches': len(ops), 'gflop': round(fl / 1e9, 1), 'frac': round(mf, 4), 'bound': 'mfma',
                           'algorithmic_gb': round(by / 1e9, 3), 'hbm_frac': round(hb, 4),
                           'ms_in_hbm_bound_ops': round(hbm_ms, 4)}
+            if stage_wall is not None:
+                # `ms` = sum of the ops' own times, one after the other on one stream; `wall_ms` = the stage in the replay the timed
+                # steps run (its lanes overlap the launches of independent ops)
+                stages[nm]['wall_ms'] = round(stage_wall[nm], 4)
+                stages[nm]['frac_wall'] = round(fl / (stage_wall[nm] * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4)
         roof['per_stage'] = stages
         out = {'metric': 'images_per_sec', 'value': total_images / dt, 'unit': 'images/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
@@ -824,11 +839,12 @@ def main():
                           'detections_per_batch_rank0': int(n_det), 'gflop_per_image': flops_fwd / B / 1e9,
                           'solver_form': args.solver_form or _default_solver_form()},
                'roofline': roof, 'multi_gpu': multi}
-        # the plan-level A/B switches this process ran with (environment, read once at import: rtm3d_amd/plan.py); all True = the product
+        # the plan-level A/B switches this process ran with (environment, read once at import: rtm3d_amd/plan.py); the product: all True
+        # but NECK_LANES (opt-in)
         from rtm3d_amd import plan as _p
         out['config']['plan_switches'] = {'FOLD_PROJECT_C128': _p.FOLD_PROJECT_C128, 'FOLD_NECK_UP': _p.FOLD_NECK_UP, 'USE_CONV64S2': _p.USE_CONV64S2,
-                                          'S2D_ONLY': _p.S2D_ONLY, 'USE_CONV128': _p.USE_CONV128}
-        if not all(out['config']['plan_switches'].values()):
+                                          'S2D_ONLY': _p.S2D_ONLY, 'USE_CONV128': _p.USE_CONV128, 'NECK_LANES': _p.NECK_LANES}
+        if not all(v for k_, v in out['config']['plan_switches'].items() if k_ != 'NECK_LANES') or out['config']['plan_switches']['NECK_LANES']:
             out['DIAGNOSTIC_plan_switches'] = 'a plan-level A/B switch is off: not the product configuration'
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'

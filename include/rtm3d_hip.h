@@ -206,6 +206,21 @@ int rtm3d_ctx_debug_read_words(rtm3d_ctx* ctx, int offset, int n, unsigned int* 
  * up on graphs - Model.forward_logits(out=...) keeps the addresses stable).  Any pointer may be NULL.                      */
 int rtm3d_ctx_graph_stats(rtm3d_ctx* ctx, int* captures, int* hits, int* enabled);
 
+/* REPLAY SCHEDULE (round 5, ABI 8).  By default every op runs on the caller's stream in the order it was recorded.  An op may be
+ * put on one of three SIDE LANES (lane 1..3: a stream the context owns) - ops of different lanes may then run at the same time,
+ * so that the fill and drain of one persistent launch overlaps another launch (the neck's three independent up-sampling chains,
+ * models/nets/keypoint_fpn_fusion.py:60-69, ride beside its top-down chain :35-46).  wait_ops: the EARLIER ops of OTHER lanes
+ * this op depends on (read-after-write, write-after-read and write-after-write on any tensor); order within a lane is the
+ * stream's.  The caller's stream continues behind every lane at the end of a replay.  Results do not depend on the schedule
+ * (every kernel is deterministic).  Graph replays (rtm3d_ctx_set_graph) and rtm3d_forward_timed ignore the lanes: plan order
+ * on one stream is a valid order of the same dependency graph.  rtm3d_ctx_set_lanes(ctx, 0) switches the lanes off (A/B).  */
+int rtm3d_op_schedule(rtm3d_ctx* ctx, int op_index, int lane, int n_wait, const int* wait_ops);
+int rtm3d_ctx_set_lanes(rtm3d_ctx* ctx, int enable);
+/* Wall time of STAGES of one eager replay with its lanes: events on the caller's stream in front of the ops mark_ops[0..n_marks)
+ * (ascending indices of lane-0 ops; n_marks <= 8) and behind the last op; h_ms[i] = mark i -> mark i + 1 (the last: -> end).   */
+int rtm3d_forward_marks(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
+                        int n_marks, const int* mark_ops, float* h_ms);
+
 /* Per-op timing of one replay with hipEvents (synchronous; for profiling/bench):
  * h_ms[i] = elapsed ms of op i; returns number of ops through *n_ops (h_ms may be NULL).          */
 int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],

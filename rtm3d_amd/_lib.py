@@ -84,6 +84,9 @@ SIGNATURES = {
     'rtm3d_ctx_debug_read_words': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'rtm3d_ctx_graph_stats': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_op_schedule': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    'rtm3d_ctx_set_lanes': (c_int, [c_void_p, c_int]),
+    'rtm3d_forward_marks': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     'rtm3d_op_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_char_p)]),
     'rtm3d_probe_set': (c_int, [c_void_p, c_int]),
     'rtm3d_probe_read': (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),

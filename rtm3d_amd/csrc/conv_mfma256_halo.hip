@@ -33,6 +33,8 @@
 #define HALO_BUF_PIECES 2912                  // buffer size: the (2*ntaps-1) slices x 8 waves x PPW lanes may overrun the halo
 #define HALO_ELEMS (HALO_BUF_PIECES * 8)
 #define HALO_MAX_BIAS 1024
+#define H_STAMP_KT 3                          // (diagnostic build -DC256_STAMPS only; the LDS has 1 KB to spare: K-tiles 4..6)
+#define H_STAMP_N 20
 
 // per group, all taps packed into one 64-bit word (4 bits per tap: dy+1 in bits 0-1, dx+1 in bits 2-3) that lives
 // in SGPRs for the whole tile: an s_load per K-tile would put its latency in front of the operand reads
@@ -53,6 +55,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                                                                 unsigned int* tile_ctr, float* stat_out) {
     __shared__ __attribute__((aligned(128))) f16 lds[WRING_ELEMS + 2 * HALO_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[HALO_MAX_BIAS + 4];     // + two ticket words
+#ifdef C256_STAMPS
+    __shared__ unsigned long long lds_stamp[2][H_STAMP_KT][H_STAMP_N];
+    int stamp_tile = 0, stamp_kt = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,12 +193,24 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         dstf[cc][0] = LDS_F16X8(wbuf + wrow_b0 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
         dstf[cc][1] = LDS_F16X8(wbuf + wrow_b1 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
     }
-#define SEG_SYNC_H(VM)                                                                          \
+// Diagnostic build only (-DC256_STAMPS, see conv_mfma256.hip): s_memtime stamps of waves 0 and 4 in the K loop of the second tile.
+#ifdef C256_STAMPS
+#define HSTAMP(k) if ((wave & 3) == 0 && stamp_tile == 1 && stamp_kt >= 4 && stamp_kt < 4 + H_STAMP_KT) { unsigned long long ts_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) :: "memory"); if (lane == 0) lds_stamp[wave >> 2][stamp_kt - 4][k] = ts_; }
+#define HSTAMP_NEXT ++stamp_kt;
+#else
+#define HSTAMP(k)
+#define HSTAMP_NEXT
+#endif
+#define SEG_SYNC_H(VM, K0)                                                                      \
+    HSTAMP((K0) + 0)                                                                            \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                           \
+    HSTAMP((K0) + 1)                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     __builtin_amdgcn_s_barrier();                                                               \
-    __builtin_amdgcn_sched_barrier(0);
-#define MMA_H(i, j, wfrag, FIRST, TAILBAR)                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    HSTAMP((K0) + 2)
+#define MMA_H(i, j, wfrag, FIRST, TAILBAR, K0)                                                  \
     __builtin_amdgcn_s_setprio(1);                                                              \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                            \
         _Pragma("unroll") for (int cc = 0; cc < 2; ++cc)                                        \
@@ -200,8 +218,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                 acc[i][j][cc][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[cc][kk], xf[p][kk], acc[i][j][cc][p], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
+    HSTAMP((K0) + 3)                                                                            \
     if (TAILBAR) __builtin_amdgcn_s_barrier();                                                  \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    HSTAMP((K0) + 4)
 // One K-tile (ch, tap).  K-tiles kt+1 / kt+2 = (ch1, tap1) / (ch2, tap2); a chunk index == CPT means chunk 0 of
 // the next tile (descriptor n, which aliases c when there is none: the re-staged data lands in free slots).
 #define STEP_H(VM, FIRST, LAST)                                                                 \
@@ -221,19 +241,20 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         LOAD_X_H(0)                                                                             \
         LOAD_W_H(wa, 0)                                                                         \
         stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);       \
-        SEG_SYNC_H(VM)                                                                          \
-        MMA_H(0, 0, wa, FIRST, 1)                                                               \
+        SEG_SYNC_H(VM, 0)                                                                       \
+        MMA_H(0, 0, wa, FIRST, 1, 0)                                                            \
         LOAD_W_H(wb, 1)                                                                         \
         stage_x(2 * tap, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                           \
-        SEG_SYNC_H(VM)                                                                          \
-        MMA_H(0, 1, wb, FIRST, 1)                                                               \
+        SEG_SYNC_H(VM, 5)                                                                       \
+        MMA_H(0, 1, wb, FIRST, 1, 5)                                                            \
         LOAD_X_H(1)                                                                             \
         stage_x(2 * tap + 1, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                       \
-        SEG_SYNC_H(VM)                                                                          \
-        MMA_H(1, 1, wb, FIRST, 1)                                                               \
+        SEG_SYNC_H(VM, 10)                                                                      \
+        MMA_H(1, 1, wb, FIRST, 1, 10)                                                           \
         stage_w(0, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);   \
-        SEG_SYNC_H(VM)                                                                          \
-        MMA_H(1, 0, wa, FIRST, !(LAST))                                                         \
+        SEG_SYNC_H(VM, 15)                                                                      \
+        MMA_H(1, 0, wa, FIRST, !(LAST), 15)                                                     \
+        HSTAMP_NEXT                                                                             \
         sp ^= 1;                                                                                \
         if (++tap == NTAP) { tap = 0; ++ch; hpar ^= 1; }                                         \
     }
@@ -372,6 +393,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
             }
         }
         if (wave >= 4) __builtin_amdgcn_s_barrier();
+#ifdef C256_STAMPS
+        ++stamp_tile; stamp_kt = 0;
+#endif
         if (!live_n) break;
         vnext = __builtin_amdgcn_readfirstlane(lds_ticket[tpar]);
         tpar ^= 1;
@@ -379,6 +403,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         wb_c = wb_n; gi_c = gi_n; nt_c = nt_n; n_c = n_n; ty_c = ty_n; tx_c = tx_n;
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();           // pair the extra barrier of waves 4-7
+#ifdef C256_STAMPS
+    if ((blockIdx.x == 0 || blockIdx.x == 101) && (wave & 3) == 0 && groups == 4 && NTAP == 9) {       // (the head conv d1)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        unsigned long long* dst = (unsigned long long*)(tile_ctr + 1024) + 2048 + (blockIdx.x ? 1 : 0) * 1024 + (wave >> 2) * 512;
+        for (int i = lane; i < H_STAMP_KT * H_STAMP_N; i += 64) dst[i] = (&lds_stamp[wave >> 2][0][0])[i];
+        if (lane == 16) dst[H_STAMP_KT * H_STAMP_N + 16] = (unsigned long long)T;
+    }
+#endif
 }
 
 // Eligibility: every tap within +-1 pixel, stride 1, 8 x 32 tiles cover the output exactly.

@@ -1062,6 +1062,66 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
     assert out['roofline'] and out['roofline']['launch_ms'] > 0 and out['roofline']['per_stage']['heads']['ms'] > 0
 
 
+def test_replay_lanes_schedule_and_bit_identity(dev):
+    """Round 5: the neck's three up-sampling chains run on side lanes of the replay (rtm3d_op_schedule).  The recorded schedule of
+    the real DLA-34 plan is the dependency structure of keypoint_fpn_fusion.py:35-69; logits with the lanes on are bit-identical to
+    the lanes off (same kernels, same tickets per lane) over repeated and interleaved replays; the stage marks of the lane replay
+    (rtm3d_forward_marks) are positive and the neck's wall time does not exceed the sum of its ops' own times by more than noise."""
+    from rtm3d_amd import plan as plan_mod
+    bb = 'DLA-34'
+    sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0)
+    m = make_model(bb, sd)
+    m.use_graph = False
+    B, H, W = 8, 128, 256
+    x = weights.synth_images(B, H, W, seed=77).to(dev)
+    was = plan_mod.NECK_LANES
+    plan_mod.NECK_LANES = True                    # (opt-in: off by default, see plan.py)
+    try:
+        plan = m._plan_for(B, H, W, dev)
+    finally:
+        plan_mod.NECK_LANES = was
+    names = plan.op_names
+    idx = {n: i for i, n in enumerate(names)}
+    lane_of = dict(zip(names, plan.lanes))
+    assert {lane_of[n] for n in names if n.startswith('fusion_up5')} == {1}
+    assert {lane_of[n] for n in names if n.startswith('fusion_up4')} == {2}
+    assert {lane_of[n] for n in names if n.startswith('fusion_up3')} == {3}
+    assert all(lane_of[n] == 0 for n in names if not n.startswith('fusion_up'))
+    w = {n: [names[j] for j in plan.waits[i]] for n, i in idx.items()}
+    assert w['fusion_up5.0'] == ['kfpn_head5']
+    assert len(w['fusion_up4.0']) == 1 and w['fusion_up4.0'][0].startswith('kfpn_up5')
+    assert len(w['fusion_up3.0']) == 1 and w['fusion_up3.0'][0].startswith('kfpn_up4')
+    assert sorted(w['kfpn_softmax_fuse']) == ['fusion_up3.0', 'fusion_up4.1', 'fusion_up5.2']
+    assert all(not w[n] for n in names if n.startswith(('backbone', 'heads')))
+    ref = None
+    for rep in range(6):
+        plan.set_lanes(rep % 2 == 0)
+        lg = [t.clone() for t in m.forward_logits(x)]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = lg
+        for a, b in zip(lg, ref):
+            assert torch.equal(a, b), rep
+    plan.set_lanes(True)
+    outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in m._head_channels]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ptrs = [o.data_ptr() for o in outs]
+    first = lambda pre: next(i for i, n in enumerate(names) if n.startswith(pre))
+    marks = [first('backbone'), first(('kfpn', 'fusion')), first('heads')]
+    wall = [plan.forward_marks(st, x.data_ptr(), ptrs, marks) for _ in range(4)][-1]
+    info = plan.forward_timed(st, x.data_ptr(), ptrs)
+    neck_sum = sum(i['ms'] for i in info if i['name'].startswith(('kfpn', 'fusion')))
+    assert all(v > 0 for v in wall) and wall[1] < neck_sum * 1.15 + 0.05, (wall, neck_sum)
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
+    lib = _lib.load()
+    bad = (ctypes.c_int * 1)(len(names))
+    assert lib.rtm3d_op_schedule(plan.ctx, 3, 1, 1, bad) != 0 and b'earlier' in lib.rtm3d_last_error()
+    assert lib.rtm3d_op_schedule(plan.ctx, 3, 7, 0, None) != 0
+    assert lib.rtm3d_forward_marks(plan.ctx, ctypes.c_void_p(st), ctypes.c_void_p(x.data_ptr()), (ctypes.c_void_p * 4)(*ptrs), 1,
+                                   (ctypes.c_int * 1)(idx['fusion_up5.0']), (ctypes.c_float * 1)()) != 0      # not a lane-0 op
+
+
 def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):
     """hipGraph replay of the plan (small batches) against the eager replay: same logits bit for bit, over several
     replays, fresh input/output buffers (new graph keys) and a second shape; the plan cache keeps at most MAX_PLANS."""

@@ -33,13 +33,23 @@ for _ in range(3):
 print('per-op ms:', '  '.join('%s %.3f' % (i['name'][-14:], i['ms']) for i in info if 'heads' in i['name']))
 lib = _lib.load()
 KT, NS = 20, 20
-buf = np.zeros(8192, np.uint32)
-_lib.check(lib.rtm3d_ctx_debug_read_words(plan.ctx, 0, 8192, buf.ctypes.data_as(ctypes.c_void_p)), 'debug_read_words')
+buf = np.zeros(16384, np.uint32)
+_lib.check(lib.rtm3d_ctx_debug_read_words(plan.ctx, 0, 16384, buf.ctypes.data_as(ctypes.c_void_p)), 'debug_read_words')
 u64 = buf.view(np.uint64)
 NAMES = ['issue+lds', 'vmcnt', 'barrier', 'mfma', 'barrier']
-for wg in range(2):
+for wg in range(4):
     for half in range(2):
         base = wg * 1024 + half * 512
+        if wg >= 2:                     # the halo kernel has LDS for three K-tiles of stamps (K-tiles 4..6)
+            st = u64[base:base + 3 * NS].reshape(3, NS).astype(np.int64)
+            if int(u64[base + 3 * NS + 16]) == 0:
+                print('d1 (halo) slot %d waves %d: no stamps' % (wg % 2, half * 4)); continue
+            per = np.zeros((3, NS)); per[:, 1:] = np.diff(st, axis=1); per[1:, 0] = st[1:, 0] - st[:-1, NS - 1]
+            mean = per[1:].mean(axis=0)
+            print('d1 (halo) workgroup slot %d, wave %d, second tile, K-tiles 5..6: cycles per K-tile %.0f (ideal 2048)' % (wg % 2, half * 4, mean.sum()))
+            for ph in range(4):
+                print('   phase %d: ' % (ph + 1) + '  '.join('%s %4.0f' % (NAMES[k], mean[ph * 5 + k]) for k in range(5)) + '   | sum %.0f' % mean[ph * 5:ph * 5 + 5].sum())
+            continue
         st = u64[base:base + KT * NS].reshape(KT, NS).astype(np.int64)
         ts = u64[base + KT * NS:base + KT * NS + 16].reshape(4, 4).astype(np.int64)
         T = int(u64[base + KT * NS + 16])
@@ -52,7 +62,7 @@ for wg in range(2):
         per[:, 1:] = np.diff(st[:T], axis=1)
         per[1:, 0] = st[1:T, 0] - st[:T - 1, NS - 1]
         mean = per[2:T - 1].mean(axis=0)
-        print('workgroup slot %d, wave %d, second tile, K-tiles 2..%d of %d: cycles per K-tile %.0f (ideal 2048)' % (wg, half * 4, T - 2, int(u64[base + KT * NS + 16]), mean.sum()))
+        print('%s workgroup slot %d, wave %d, second tile, K-tiles 2..%d of %d: cycles per K-tile %.0f (ideal 2048)' % ('d6 (generic)' if wg < 2 else 'd1 (halo)', wg % 2, half * 4, T - 2, int(u64[base + KT * NS + 16]), mean.sum()))
         for ph in range(4):
             print('   phase %d: ' % (ph + 1) + '  '.join('%s %4.0f' % (NAMES[k], mean[ph * 5 + k]) for k in range(5)) + '   | sum %.0f' % mean[ph * 5:ph * 5 + 5].sum())
         for ti in range(4):
