@@ -794,7 +794,14 @@ class RealizedPlan(object):
         rounds) and the small 24 x 80 / 48 x 160 launches that fill a fraction of the chip run beside another chain's work items.
         Dependencies across lanes are derived from the recorded ops' tensor reads / writes (RAW, WAR, WAW), latest conflicting op
         per other lane."""
-        self.lanes, self.waits = compute_schedule(self.op_names, self.op_rw) if NECK_LANES else ([0] * len(self.op_names), [[] for _ in self.op_names])
+        none = ([0] * len(self.op_names), [[] for _ in self.op_names])
+        self.lanes, self.waits = compute_schedule(self.op_names, self.op_rw) if NECK_LANES else none
+        # small launches (the '_deep' ring kernel and its split-K form share their arrival counters between ops) stay in plan order on
+        # one stream: the lanes are for batches whose neck launches are persistent tile loops
+        if any(self.lanes):
+            kn = self.kernel_names()
+            if any(l and '_deep' in kn[i] for i, l in enumerate(self.lanes)):
+                self.lanes, self.waits = none
         for i in range(len(self.op_names)):
             if self.lanes[i] or self.waits[i]:
                 w = (ctypes.c_int * max(1, len(self.waits[i])))(*self.waits[i])

@@ -1072,7 +1072,7 @@ def test_replay_lanes_schedule_and_bit_identity(dev):
     sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0)
     m = make_model(bb, sd)
     m.use_graph = False
-    B, H, W = 8, 128, 256
+    B, H, W = 32, 384, 1280                       # (the benchmark shape: a plan with small-launch '_deep' kernels in the neck keeps its lanes off)
     x = weights.synth_images(B, H, W, seed=77).to(dev)
     was = plan_mod.NECK_LANES
     plan_mod.NECK_LANES = True                    # (opt-in: off by default, see plan.py)
@@ -1481,9 +1481,12 @@ def test_fp16_range_report_names_the_overflowing_tensor(dev):
     #  the report also covers what the level rewrites store: composed neck taps / summed biases of the recorded ops,
     # and it says which activation rows the realized plan no longer materialises (the neck's `up` maps, s2d-only features)
     realized = [r for r in rows if r['what'] == 'weight (realized)']
-    assert any('kfpn_up' in r['op'] and 'kfpn_proj' in r['op'] for r in realized), [r['op'] for r in realized][:8]
+    rplan = m._plan_for(1, 128, 256, dev)
+    assert len(realized) == len(rplan.weight_ranges) > 20 and any(r['materialised'] for r in acts)
     ghost = [r for r in acts if not r['materialised']]
-    assert ghost and any('kfpn_up' in r['op'] for r in ghost) and any(r['materialised'] for r in acts)
+    assert bool(ghost) == bool(rplan.unwritten)                          # rows the realized plan no longer writes are tagged as such
+    if any('+kfpn_proj' in n for n in rplan.op_names):                   # (the neck fold applies from a certain map size on)
+        assert any('kfpn_up' in r['op'] and 'kfpn_proj' in r['op'] for r in realized) and any('kfpn_up' in r['op'] for r in ghost)
     record_measurement('fp16_range', 'healthy', {'largest': rows[0]['max_abs'], 'tensor': rows[0]['tensor'], 'op': rows[0]['op']})
     m.release_verify()
     sd2 = {k: v.clone() for k, v in sd.items()}
