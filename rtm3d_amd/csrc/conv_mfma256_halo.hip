@@ -101,7 +101,24 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     // bit-reproducible.)
     const int NSL = 2 * NTAP - 1;
     const int PPW = ((HALO_PIECES + 8 * NSL - 1) / (8 * NSL) + 3) & ~3;           // <= 64 for NTAP >= 4
-    const bool xlane_on = lane < PPW;
+    // Round 5, 3x3 layers (NTAP == 9: 18 slots per chunk): a slice is ONE HALO ROW - 34 pixels x 8 pieces = 272 = 8 waves x 34
+    // lanes - so a lane's source offset is the same in every slice but for a wave-uniform row offset and the row's parity in
+    // the swizzle key (two registers for the whole kernel).  The piece-linear slices above cost ~17 vector instructions per
+    // slice (a division by 34 among them) in the load segments of phases 2 and 3, which is what the partner wave's MFMA
+    // segment waits for (in-kernel stamps: 380 / 410 cycles against 200 / 305 in the generic kernel).  Rows 0 .. 9 ride in
+    // slots 0 .. 9, the other eight slots re-stage row 0 (same bytes, a buffer nobody reads yet).  The LDS image is unchanged
+    // (piece p = row * 272 + pixel * 8 + chunk at p * 16 bytes).  The transposed convs (NTAP == 4: 7 slots < 10 rows) keep
+    // the piece-linear slices.
+    const bool rowsl = NTAP == 9;
+    const bool xlane_on = rowsl ? lane < 34 : lane < PPW;
+    uint32_t roff_e, roff_o;
+    {
+        const int rp = wave * 34 + (lane < 34 ? lane : 33);
+        const int rhx = rp >> 3, rhcs = rp & 7;
+        roff_e = (uint32_t)(rhx * a.in_C + ((rhcs ^ (rhx & 7)) * 8));             // even halo row: key = hx & 7
+        roff_o = (uint32_t)(rhx * a.in_C + ((rhcs ^ ((rhx ^ 4) & 7)) * 8));       // odd halo row:  key = (hx ^ 4) & 7
+    }
+    const int row_pitch = a.in_Wp * a.in_C;
 
     // tile descriptors (current / next): halo origin in the input tensor, weight base, indices
     size_t xb_c, xb_n;                      // element offset of halo pixel (0,0), channel 0 of the group slice
@@ -127,6 +144,13 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
     // halo slice s (0 .. 2*NTAP-1) of chunk ch of tile base xb into halo buffer hp
     auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
+        if (rowsl) {
+            const int r = sidx < 10 ? sidx : 0;
+            const f16* src = a.in + xb + ch * 64 + (ptrdiff_t)(r * row_pitch) + ((r & 1) ? roff_o : roff_e);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + (r * 272 + wave * 34) * 8) * 2u);
+            if (xlane_on) DMA16(src, dst);
+            return;
+        }
         const int p0 = ((sidx == NSL ? 0 : sidx) * 8 + wave) * PPW;   // first piece of this wave's run
         // Every wave issues this instruction with its first PPW lanes in every call - a wave that skipped
         // it would count one DMA less than vmcnt(6) assumes and read a weight tile before it has landed.
