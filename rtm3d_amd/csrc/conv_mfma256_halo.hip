@@ -234,29 +234,52 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     __builtin_amdgcn_s_barrier();                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     HSTAMP((K0) + 2)
-#define MMA_H(i, j, wfrag, FIRST, TAILBAR, K0)                                                  \
+#define MMA_H(i, j, wfrag, FIRST, TAILBAR, K0) MMA_HX(i, j, wfrag, FIRST, TAILBAR, K0, , )
+#define MMA_HX(i, j, wfrag, FIRST, TAILBAR, K0, PRE, PIN)                                       \
     __builtin_amdgcn_s_setprio(1);                                                              \
+    PRE                                                                                         \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                            \
         _Pragma("unroll") for (int cc = 0; cc < 2; ++cc)                                        \
             _Pragma("unroll") for (int p = 0; p < 4; ++p)                                       \
                 acc[i][j][cc][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfrag[cc][kk], xf[p][kk], acc[i][j][cc][p], 0, 0, 0); \
+    PIN                                                                                         \
     __builtin_amdgcn_s_setprio(0);                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     HSTAMP((K0) + 3)                                                                            \
     if (TAILBAR) __builtin_amdgcn_s_barrier();                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     HSTAMP((K0) + 4)
+// LDS addresses of this lane's pixel-operand fragments for tap `tp` of the halo in buffer hp (xu / xw: the two k-half slots of an
+// even halo row; LOAD_X_H swaps them on odd rows).  Round 5: computed beside the MFMAs of phase 4 for the NEXT K-tile (six
+// full-rate vector instructions that fit the MFMA gaps) instead of at the head of phase 1's load segment, whose reads wait for them.
+#define HALO_XADDR(TW, TP, HP, XU, XW)                                                          \
+    {                                                                                           \
+        const uint32_t hb_ = lds_base + (uint32_t)(WRING_ELEMS + (HP) * HALO_ELEMS) * 2;          \
+        const int tbits_ = (int)((TW) >> (4 * (TP))) & 15;                                      \
+        const int dys_ = (tbits_ & 3) - 1, dxs_ = (tbits_ >> 2) - 1;                              \
+        const uint32_t ck_ = dxs_ < 0 ? ck_m : (dxs_ > 0 ? ck_p : ck_0);                          \
+        const uint32_t xt0_ = hb_ + xlane + (uint32_t)((dys_ * HALO_W + dxs_) * 128) + ck_;       \
+        XU = xt0_ ^ (uint32_t)(((1 + dys_) & 1) << 6); XW = XU ^ 64u;                            \
+    }
+#define HALO_XADDR_NOW const uint32_t xu = xu_c, xw = xw_c;
+#define HALO_XADDR_NEXT                                                                         \
+    {                                                                                           \
+        int tapn_ = tap + 1, hparn_ = hpar;                                                     \
+        unsigned long long twn_ = tapword;                                                      \
+        if (tapn_ == NTAP) { tapn_ = 0; hparn_ ^= 1; if (ch + 1 == CPT) twn_ = ht.taps[gi_n]; }  \
+        HALO_XADDR(twn_, tapn_, hparn_, xu_c, xw_c)                                             \
+    }
+#define HALO_XADDR_PIN asm volatile("" : "+v"(xu_c), "+v"(xw_c));
+// (Same-box A/Bs of round 5 on this kernel, heads.conv_d1 / fusion_up5.2 / kfpn_up3 ms: addresses a K-tile ahead 3.63 / 0.500 / 0.464
+// against 3.64 / 0.507 / 0.470 computed in place - kept; a load segment's DMA issued in FRONT of its operand reads instead of
+// behind them 3.85 / 0.547 / 0.465 - the reads then queue behind the DMA's address path; the halo-slice source addresses
+// computed beside the MFMAs 4.02 / 0.527 / 0.469: their quarter-rate integer instructions outlast the MFMA gaps - rejected.)
 // One K-tile (ch, tap).  K-tiles kt+1 / kt+2 = (ch1, tap1) / (ch2, tap2); a chunk index == CPT means chunk 0 of
 // the next tile (descriptor n, which aliases c when there is none: the re-staged data lands in free slots).
 #define STEP_H(VM, FIRST, LAST)                                                                 \
     {                                                                                           \
-        const uint32_t hb = lds_base + (uint32_t)(WRING_ELEMS + hpar * HALO_ELEMS) * 2;          \
         const uint32_t wbuf = lds_base + (uint32_t)sp * (2 * HALF_ELEMS * 2);                    \
-        const int tbits = (int)(tapword >> (4 * tap)) & 15;                                     \
-        const int dys = (tbits & 3) - 1, dxs = (tbits >> 2) - 1;                                 \
-        const uint32_t ck = dxs < 0 ? ck_m : (dxs > 0 ? ck_p : ck_0);                            \
-        const uint32_t xt0 = hb + xlane + (uint32_t)((dys * HALO_W + dxs) * 128) + ck;           \
-        const uint32_t xu = xt0 ^ (uint32_t)(((1 + dys) & 1) << 6), xw = xu ^ 64u;               \
+        HALO_XADDR_NOW                                                                          \
         int tap1 = tap + 1, ch1 = ch;                                                           \
         if (tap1 == NTAP) { tap1 = 0; ch1 = ch + 1; }                                            \
         int tap2 = tap1 + 1, ch2 = ch1;                                                         \
@@ -277,12 +300,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         MMA_H(1, 1, wb, FIRST, 1, 10)                                                           \
         stage_w(0, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);   \
         SEG_SYNC_H(VM, 15)                                                                      \
-        MMA_H(1, 0, wa, FIRST, !(LAST), 15)                                                     \
+        MMA_HX(1, 0, wa, FIRST, !(LAST), 15, HALO_XADDR_NEXT, HALO_XADDR_PIN)                   \
         HSTAMP_NEXT                                                                             \
         sp ^= 1;                                                                                \
         if (++tap == NTAP) { tap = 0; ++ch; hpar ^= 1; }                                         \
     }
 
+    uint32_t xu_c, xw_c;                    // this lane's pixel-operand fragment addresses of the NEXT K-tile to run (HALO_XADDR_NEXT)
+    HALO_XADDR(ht.taps[gi_c], 0, 0, xu_c, xw_c)
     for (;;) {
         // ticket of the tile after next (see conv_mfma256_persistent_kernel)
         int ticket = vnext;
