@@ -12,6 +12,14 @@
 //   lds256  one wave per SIMD, 128 x 128 wave tile: 16 ds_read_b128 per 64 MFMAs (256 B per MFMA), fragments of step k+1
 //           read while step k multiplies
 //   lds384b lds384 with the conv kernels' two raw barriers per 16-MFMA phase and waves 4-7 one barrier behind
+//   dma_l2 / dma_mall / dma_hbm   lds384b + the conv kernels' 64 KB of LDS-DMA per K-tile: all from L2; the pixel half from a 1 MB
+//           window per workgroup (Infinity Cache); from an 8 MB window (HBM)
+//   1w_lds / 1w_dma / 1w_mall   one wave per SIMD on a 128 x 128 wave tile, fragment sets ping-ponging per 32-deep K half, reads
+//           and DMA pieces written between groups of eight MFMAs (mfma_rate_1w_kernel): what that layout gives in HIP C++
+// Measured (profiles/r05_mfma_rate_random.txt): reg2 1.91 PF at 1.88 GHz, lds384b 1.70, dma_l2 1.45 (pipe 0.85 busy at 1.68 GHz),
+// dma_hbm 1.14 (1.36 GHz); 1w_lds 1.60 (pipe 0.74: the compiler shuffles fragments through AGPRs), 1w_dma 0.96 (pipe 0.40: the
+// only wave of a SIMD pays every DMA issue and every wait itself) - the one-wave layout needs loader waves of its own and a
+// hand-scheduled MFMA stream before it can be compared with the 8-wave loop.
 // Reported per variant: ms per launch, TFLOP/s, the in-kernel clock (s_memtime / s_memrealtime around the loop, median over
 // waves, MI355X_MICROARCH.md "DVFS give-back" item 6) and the matrix-pipe occupancy that clock implies (16 cycles per MFMA and
 // SIMD).  >= 2.5 s of back-to-back launches run before the timed ones.  Under `rocprofv3 --pmc GRBM_GUI_ACTIVE
@@ -151,6 +159,94 @@ __global__ __launch_bounds__(WAVES * 64) void mfma_rate_kernel(const f16* __rest
     if (lane == 0) stamps[blockIdx.x * WAVES + wave] = Stamp{c0, r0, c1, r1};
 }
 
+// One wave per SIMD, 128 x 128 wave tile, written the way a kernel on that tile would have to be (round 5, for DESIGN section 8:
+// is the "256 LDS bytes per MFMA" layout worth a rewrite of the conv256 family?).  Two fragment register sets ping-pong per
+// 32-deep K half: while the 64 MFMAs of one half run on set A, the 16 fragments of the next half are read into set B, two per
+// group of eight MFMAs (written in that order: the MFMAs of a group do not depend on the reads beside them).  DMA = 1: the same
+// 64 KB of LDS-DMA per K-tile as the 8-wave loop (16 pieces per wave and K-tile, one per group), one barrier per K-tile behind the
+// counted wait that retires the next K-tile's pieces.  Accumulators: 64 tiles = 256 registers (AGPRs), fragments 128.
+template <int DMA>
+__global__ __launch_bounds__(256) void mfma_rate_1w_kernel(const f16* __restrict__ rnd, float* __restrict__ out, Stamp* __restrict__ stamps, int steps,
+                                                           const f16* __restrict__ dma_w, const f16* __restrict__ dma_x, unsigned x_window) {
+    __shared__ __attribute__((aligned(16))) f16 lds[LDS_BYTES / 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const f16x8* src = (const f16x8*)(rnd + ((size_t)blockIdx.x % 128) * (LDS_BYTES / 2));
+        for (int i = tid; i < LDS_BYTES / 16; i += 256) ((f16x8*)lds)[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int xw = wave & 1, ww = wave >> 1;
+    uint32_t xrow[2], wrow[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fk) ^ (frow & 7)) * 8;
+        xrow[kk] = (uint32_t)((((xw * 128) + frow) * 64 + sw) * 2);
+        wrow[kk] = (uint32_t)(((256 + ww * 128 + frow) * 64 + sw) * 2);
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 xa[8], wa[8], xb[8], wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xa[i] = LDS_F16X8(lds_base + xrow[0] + i * 2048); wa[i] = LDS_F16X8(lds_base + wrow[0] + i * 2048); }
+    unsigned xpos = 0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t bufb = lds_base;
+    for (int s = 0; s < steps; ++s) {
+        const uint32_t nb = lds_base + ((bufb - lds_base) ^ (64 * 1024));
+        // piece g (0..15) of this wave's share of the NEXT-BUT-ONE K-tile's 64 KB -> the buffer the first half just finished reading
+#define DMA_PIECE(g, dstbuf) if (DMA) { \
+            const int q_ = wave * 16 + (g); \
+            const f16* src_ = q_ < 32 ? dma_x + (size_t)blockIdx.x * (x_window / 2) + (size_t)((xpos + q_ * 512) % (x_window / 2)) \
+                                      : dma_w + (size_t)(((s & 15) * 32 + (q_ - 32)) * 512); \
+            DMA16(src_ + lane * 8, __builtin_amdgcn_readfirstlane((dstbuf) + (uint32_t)(q_ * 1024))); }
+        // ---- K half 0: MFMAs on set A (xa, wa), reads of this K-tile's half 1 into set B; DMA pieces 8..15 of the K-tile that goes into nb ... see below
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            DMA_PIECE(8 + c, nb)          // second half of the pieces of K-tile s + 1 (nb was released by the barrier of step s - 1)
+            xb[c] = LDS_F16X8(bufb + xrow[1] + c * 2048);
+            wb[c] = LDS_F16X8(bufb + wrow[1] + c * 2048);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c], xa[p], acc[c][p], 0, 0, 0);
+        }
+        // every piece of K-tile s + 1 has landed (this wave's 16), every wave is done reading bufb's half-1 fragments... the barrier publishes both
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- K half 1: MFMAs on set B, reads of the NEXT K-tile's half 0 (buffer nb) into set A; DMA pieces 0..7 of K-tile s + 2 into bufb
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            DMA_PIECE(c, bufb)
+            xa[c] = LDS_F16X8(nb + xrow[0] + c * 2048);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[c], xb[p], acc[c][p], 0, 0, 0);
+            wa[c] = LDS_F16X8(nb + wrow[0] + c * 2048);
+        }
+        if (DMA) xpos += 32 * 512;
+        bufb = nb;
+        asm volatile("" : "+s"(bufb));
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) sum += acc[c][p][0] + acc[c][p][1] + acc[c][p][2] + acc[c][p][3];
+    out[(size_t)blockIdx.x * 256 + tid] = sum;
+    if (lane == 0) stamps[blockIdx.x * 4 + wave] = Stamp{c0, r0, c1, r1};
+}
+template <int DMA>
+static void launch_1w(const f16* rnd, float* out, Stamp* st, int steps, hipStream_t s, const f16* dw, const f16* dx, unsigned xw) {
+    hipLaunchKernelGGL((mfma_rate_1w_kernel<DMA>), dim3(256), dim3(256), 0, s, rnd, out, st, steps, dw, dx, xw);
+}
+
 struct Variant { const char* name; int waves; int lds_bytes_per_mfma; void (*launch)(const f16*, float*, Stamp*, int, hipStream_t, const f16*, const f16*, unsigned); unsigned x_window; };
 
 template <int MODE, int NX, int NW, int WAVES>
@@ -193,6 +289,9 @@ int main(int argc, char** argv) {
         {"dma_l2 (lds384b + 64 KB LDS-DMA per K-tile, L2 hits)", 8, 384, launch<3, 8, 4, 8>, 128u << 10},
         {"dma_mall(same, pixels: 1 MB window per workgroup)   ", 8, 384, launch<3, 8, 4, 8>, 1u << 20},
         {"dma_hbm (same, pixels: 8 MB window per workgroup)   ", 8, 384, launch<3, 8, 4, 8>, 8u << 20},
+        {"1w_lds (1 wave/SIMD 128x128, hand-ordered, 256 B)    ", 4, 256, launch_1w<0>, 0},
+        {"1w_dma (same + 64 KB LDS-DMA per K-tile, L2 hits)    ", 4, 256, launch_1w<1>, 128u << 10},
+        {"1w_mall(same, pixels: 1 MB window per workgroup)     ", 4, 256, launch_1w<1>, 1u << 20},
     };
     printf("%-54s %9s %9s %9s %9s\n", "variant", "ms/launch", "TFLOP/s", "clock GHz", "pipe busy");
     for (const Variant& v : vs) {
