@@ -8,9 +8,9 @@ O=$R/gpurun_out/mfma_rate
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BIN=$R/tools/microbench/mfma_rate.out
-timeout -k 10 120 $BIN 2.5 4000 0 > $O/random.txt 2>&1 || { tail -5 $O/random.txt; exit 1; }
+timeout -k 10 200 $BIN 2.5 4000 0 > $O/random.txt 2>&1 || { tail -5 $O/random.txt; exit 1; }
 cat $O/random.txt
-timeout -k 10 120 $BIN 2.5 4000 1 > $O/zeros.txt 2>&1 || { tail -5 $O/zeros.txt; exit 1; }
+timeout -k 10 200 $BIN 2.5 4000 1 > $O/zeros.txt 2>&1 || { tail -5 $O/zeros.txt; exit 1; }
 cat $O/zeros.txt
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc -o pmc -- $BIN 1.0 4000 0 > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; exit 1; }
 find $O -name "*.db" -delete
