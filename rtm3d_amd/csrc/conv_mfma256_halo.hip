@@ -125,6 +125,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const f16 *wb_c, *wb_n;
     int gi_c, gi_n, nt_c, nt_n, n_c, n_n, ty_c, ty_n, tx_c, tx_n;
     auto locate = [&](int vv, size_t& xb, const f16*& wb, int& gi, int& nt, int& n, int& ty, int& tx) {
+        // (group-major order.  Round 5, same-box A/B: the four sub-pixel phases of a transposed conv - which read the SAME input
+        // halo - on consecutive tickets instead, so that three of four halo fetches hit L2: no change, 0.507 vs 0.506 ms, although
+        // these launches fetch their input 4-5 times over, 0.63 GB against 0.13 GB: the fabric traffic is not what they wait for.)
         gi = vv / jbs;
         const int jb = vv - gi * jbs;
         const int q = jb / a.NT;
