@@ -491,6 +491,10 @@ hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int 
     const int chunk = (a.MT + 7) / 8;
     int per_xcd = cu_count / 8;
     if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+#ifdef HALO_T_NOSTATS
+    stat_out = nullptr;     // (timing only: what do the softmax partials cost their producers?  round 5, same box: 0.504 / 0.510 / 0.513 ms
+                            //  with them, 0.467 / 0.475 / 0.486 without = 2.3 us of a 31 us tile, 128 v_exp_f32 per lane)
+#endif
     if (stat_out) hipLaunchKernelGGL(conv_mfma256_halo_kernel<1>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
     else hipLaunchKernelGGL(conv_mfma256_halo_kernel<0>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
     return hipGetLastError();
