@@ -386,6 +386,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                         const auto s0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef HALO_T_NOSTORE
+                        if (a.relu == 12345)        // (timing only: the epilogue without its 16 stores per lane.  Round 5, same box: heads.conv_d1
+                                                    //  3.76 -> 3.62 ms (2 GB written), the 96 x 320 transposed convs 0.523 -> 0.510: what hiding the stores could buy)
+#endif
                         *(u32x4*)((f16*)a.out + opix[p] + j * 128) = o;
                     }
             }
