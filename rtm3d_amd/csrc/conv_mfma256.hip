@@ -333,6 +333,18 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 #define SEG_SYNC_S(VM, K0) SEG_SYNC_N(VM)
 #define MMA_S(i, j, wfrag, FIRST, TAILBAR, K0) MMA_N(i, j, wfrag, FIRST, TAILBAR)
 #endif
+// Where WB's DMA is issued.  Phase 1 of the K-tile before its use (12 operand reads in the same load segment), or - with
+// -DC256_WB_IN_P4 - phase 4 of the K-tile before that (no operand reads there; legal with the same counted waits: its target
+// half was last read in phase 2).  Same box, round 5: the halo kernel gains 3 % from the move (heads.conv_d1 3.64 -> 3.54 ms),
+// this kernel loses 0.7 % (heads.conv_d6 3.547 -> 3.572, backbone 2.31 -> 2.33): here phase 4 already carries the tap-table
+// lookup and every phase stages two DMAs, so the move only unbalances them.  Kept in phase 1.
+#ifndef C256_WB_IN_P4
+#define STAGE_WB_P1 stage(SLOT_WB, t + 1, sp ^ 1, 0);
+#define STAGE_WB_P4
+#else
+#define STAGE_WB_P1
+#define STAGE_WB_P4 stage(SLOT_WB, t + 2, sp, 0);
+#endif
 #define STEP_N(VM, FIRST, LAST)                                                             \
     {                                                                                       \
         const uint32_t bufb = lds_base + (uint32_t)sp * (BUF_ELEMS * 2);                    \
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         const uint32_t waddr0 = bufb + wrow_b0, waddr1 = bufb + wrow_b1;                    \
         LOAD_X_N(SLOT_XA)                                                                   \
         LOAD_W_N(wa, SLOT_WA)                                                               \
-        stage(SLOT_WB, t + 1, sp ^ 1, 0);                                                   \
+        STAGE_WB_P1                                                                         \
         SEG_SYNC_S(VM, 0)                                                                   \
         MMA_S(0, 0, wa, FIRST, 1, 0)                                                        \
         LOAD_W_N(wb, SLOT_WB)                                                               \
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         int kchan3;                                                                         \
         int kraw3 = koff_parts(t + 3, kchan3);                                              \
         stage(SLOT_WA, t + 2, sp, 0);                                                       \
+        STAGE_WB_P4                                                                         \
         SEG_SYNC_S(VM, 15)                                                                  \
         asm volatile("" : "+s"(kraw3));           /* first use of the loaded word: behind the segment's wait */ \
         const int koff3 = kraw3 + kchan3;                                                   \
@@ -504,7 +517,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     // ---- prologue (once per workgroup): tile 0 complete, XA(1), WA(1) in flight
     stage(SLOT_XA, 0, 0, koff_of(0)); stage(SLOT_WA, 0, 0, 0); stage(SLOT_WB, 0, 0, 0); stage(SLOT_XB, 0, 0, koff_of(0));
     stage(SLOT_XA, 1, 1, koff_of(1)); stage(SLOT_WA, 1, 1, 0);
+#ifndef C256_WB_IN_P4
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
+    stage(SLOT_WB, 1, 1, 0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
@@ -512,6 +530,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     int sp = 0;                                           // LDS buffer of the current K-tile
     int tpar = 0;
     int koff1 = koff_of(1), koff2 = koff_of(2);           // T >= 4: both inside the first tile
+    bool first_tile = true;
 
     for (;;) {
         // draw the ticket of the tile after next (unless the last draw already came back empty); it is
@@ -537,7 +556,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                     for (int p = 0; p < 4; ++p) acc[i][j][c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int t = 0;
         TSTAMP(0)
-        STEP_N(24, 1, 0)
+        // The first K-tile's waits count the previous tile's 16 stores as well.  The workgroup's FIRST tile has none before it: with
+        // the same count its waits would let the prologue's K-tile-1 half-tiles stay in flight past their first read.
+        if (first_tile) STEP_N(8, 1, 0) else STEP_N(24, 1, 0)
+        first_tile = false;
         if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(ticket) : : "memory");
             if (lane == 0) {

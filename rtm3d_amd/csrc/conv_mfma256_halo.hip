@@ -15,7 +15,7 @@
 // Differences: the weight ring holds only WA/WB half-tiles (64 KB); the halo of the NEXT chunk (or of the
 // next tile's first chunk) is staged in 2*ntaps-1 equal slices, one DMA instruction per wave in each P2 and
 // P3 (<= 64 lanes active, source address computed on the fly from the slice index), so that every K-tile
-// issues the same 2+1+1+2 DMA instructions and the counted s_waitcnt stays an immediate (vmcnt(6)).
+// issues the same 0+1+1+4 DMA instructions (P4: WA and WB of K-tile kt+2) and the counted s_waitcnt stays an immediate (vmcnt(6)).
 // When there is no next tile the same instructions re-stage data of the current tile into ring slots
 // that are already free: no dummy slot (the LDS is full) and no run-time counts.  (First version: six
 // 512-lane halo DMAs on taps 0-2 and per-phase counts dispatched through a switch: the scalar code of
@@ -194,11 +194,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const f16 lo = a.relu ? (f16)0.f : (f16)(-__builtin_inff());
     const f16x4 lo4 = {lo, lo, lo, lo};
 
-    // ---- prologue (once per workgroup): halo of chunk 0, WA(0), WB(0), WA(1); everything lands
+    // ---- prologue (once per workgroup): halo of chunk 0, WA(0), WB(0), WA(1), WB(1); everything lands
     for (int sidx = 0; sidx < 2 * NTAP; ++sidx) stage_x(sidx, xb_c, 0, 0);
     stage_w(0, wb_c, 0, 0);
     stage_w(1, wb_c, 0, 0);
     stage_w(0, wb_c, CPT, 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
+#ifndef HALO_WB_IN_P1
+    stage_w(1, wb_c, CPT, 1);
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
@@ -279,6 +282,18 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 // computed beside the MFMAs 4.02 / 0.527 / 0.469: their quarter-rate integer instructions outlast the MFMA gaps - rejected.)
 // One K-tile (ch, tap).  K-tiles kt+1 / kt+2 = (ch1, tap1) / (ch2, tap2); a chunk index == CPT means chunk 0 of
 // the next tile (descriptor n, which aliases c when there is none: the re-staged data lands in free slots).
+// WB's DMA is issued in phase 4 of the K-tile two before its use, next to WA's (a load segment without operand reads), not in
+// phase 1 of the K-tile before (behind 12 operand reads): its target half was last read in phase 2, and with six DMA
+// instructions per K-tile either way the counted waits retire every half-tile at the same barrier as before.  Same box, round 5,
+// three interleaved rounds: heads.conv_d1 3.665 / 3.702 / 3.669 -> 3.558 / 3.549 / 3.561 ms, fusion_up5.2 0.510 -> 0.500,
+// kfpn_up3 0.468 -> 0.471 (-DHALO_WB_IN_P1 restores the old order for A/Bs).
+#ifdef HALO_WB_IN_P1
+#define STAGE_WB_P1 stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);
+#define STAGE_WB_P4
+#else
+#define STAGE_WB_P1
+#define STAGE_WB_P4 stage_w(1, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);
+#endif
 #define STEP_H(VM, FIRST, LAST)                                                                 \
     {                                                                                           \
         const uint32_t wbuf = lds_base + (uint32_t)sp * (2 * HALF_ELEMS * 2);                    \
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         const bool xn = ch + 1 == CPT;               /* the halo staged now is the next tile's chunk 0 */ \
         LOAD_X_H(0)                                                                             \
         LOAD_W_H(wa, 0)                                                                         \
-        stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);       \
+        STAGE_WB_P1                                                                             \
         SEG_SYNC_H(VM, 0)                                                                       \
         MMA_H(0, 0, wa, FIRST, 1, 0)                                                            \
         LOAD_W_H(wb, 1)                                                                         \
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         SEG_SYNC_H(VM, 10)                                                                      \
         MMA_H(1, 1, wb, FIRST, 1, 10)                                                           \
         stage_w(0, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);   \
+        STAGE_WB_P4                                                                             \
         SEG_SYNC_H(VM, 15)                                                                      \
         MMA_HX(1, 0, wa, FIRST, !(LAST), 15, HALO_XADDR_NEXT, HALO_XADDR_PIN)                   \
         HSTAMP_NEXT                                                                             \
