@@ -286,7 +286,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 // phase 1 of the K-tile before (behind 12 operand reads): its target half was last read in phase 2, and with six DMA
 // instructions per K-tile either way the counted waits retire every half-tile at the same barrier as before.  Same box, round 5,
 // three interleaved rounds: heads.conv_d1 3.665 / 3.702 / 3.669 -> 3.558 / 3.549 / 3.561 ms, fusion_up5.2 0.510 -> 0.500,
-// kfpn_up3 0.468 -> 0.471 (-DHALO_WB_IN_P1 restores the old order for A/Bs).
+// kfpn_up3 0.468 -> 0.471 (-DHALO_WB_IN_P1 restores the old order for A/Bs).  The halo slices do not follow: the second slice beside
+// the first in phase 2 (phase 3 then only reads) 3.51 -> 3.72 ms, both slices in phase 4 (all six DMAs in the read-free segment,
+// phases 1-3 only read) 3.51 -> 3.57 and fusion_up5.2 0.50 -> 0.56 - one slice behind the reads of phases 2 and 3 each stays.
 #ifdef HALO_WB_IN_P1
 #define STAGE_WB_P1 stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);
 #define STAGE_WB_P4
