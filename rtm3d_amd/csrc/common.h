@@ -40,6 +40,9 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
 #define RT_DMA16_SBASE(voff_bytes, sbase, lds_byte_addr) \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
 
+#define RT_DMA16_SBASE_NT(voff_bytes, sbase, lds_byte_addr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
+
 #define RT_MAX_GROUPS 4
 #define RT_MAX_TAPS 80
 

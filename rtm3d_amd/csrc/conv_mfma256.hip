@@ -242,6 +242,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // handed to a ds_read whose data lands before a queued MFMA has read them as SrcC: conv_mfma256_halo.hip).
 #define DMA16 RT_DMA16                              // common.h: the one LDS-DMA definition
 #define DMA16_NT RT_DMA16_NT
+#define DMA16_SBASE RT_DMA16_SBASE
+#define DMA16_SBASE_NT RT_DMA16_SBASE_NT
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LOAD_X_N(SLOT)                                                                      \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                         \
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                 const int n = div_small_q(m, a.HmWm, rcp_hw), rem = m - n * a.HmWm;
                 const int y = div_small_q(rem, a.Wm, rcp_w), x = rem - y * a.Wm;
                 const uint32_t pix = (uint32_t)((n * a.in_Hp + y * a.in_stride + a.in_P) * a.in_Wp + x * a.in_stride + a.in_P);
-                xo[h][i] = pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8);
+                xo[h][i] = (pix * (uint32_t)a.in_C + (uint32_t)g.in_coff + (uint32_t)((cs ^ (rr & 7)) * 8)) * 2u;      // BYTES
             }
 #ifdef C256_T_WSAME
         wb = a.wgt + g.w_off;        // timing-only: every tile streams channel tile 0's weights (L2-resident for sure)
@@ -477,6 +479,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         return a.g[in_cur ? gi_c : gi_n].tap_off[tap];
     };
     auto koff_of = [&](int kpos) -> int { int c; const int r = koff_parts(kpos, c); return r + c; };
+    // Sources are a wave-uniform 64-bit base in SGPRs plus a 32-bit byte offset per lane (xo_* / wvoff, fixed for the tile): no
+    // 64-bit vector address arithmetic in the load segments (round 5: two to four VALU instructions per DMA before, two of them
+    // 64-bit adds).  The launcher keeps tensors past 4 GB off this kernel.
+    const uint32_t wvoff = (uint32_t)tid * 16u;
     auto stage = [&](int slot, int kpos, int par, int koff) {
         const bool in_cur = kpos < T;
         const int k = in_cur ? kpos : kpos - T;
@@ -485,12 +491,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 #ifdef C256_T_NOX
             return;
 #endif
+            const f16* xbase = a.in + (ptrdiff_t)koff;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t xo = in_cur ? xo_c[slot][i] : xo_n[slot][i];
-                const f16* src = a.in + (size_t)xo + (ptrdiff_t)koff;
-                if (XNT) DMA16_NT(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
-                else DMA16(src, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                if (XNT) DMA16_SBASE_NT(xo, xbase, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                else DMA16_SBASE(xo, xbase, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
             }
         } else {
 #ifdef C256_T_NOW
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                DMA16(ws + (i * 512 + tid) * 8, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+                DMA16_SBASE(wvoff, ws + i * 512 * 8, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
         }
     };
 
@@ -690,7 +696,10 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
     int nbias = 0;
     for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
     nbias = (nbias + 255) / 256 * 256;      // channel tiles read whole 256-float runs (the bias array is padded to that)
-    if (a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr) {
+    // the persistent kernel addresses its pixel operand as SGPR base + 32-bit byte offset per lane: inputs of 4 GB and more
+    // (bs = 32 tops out at 2.07 GB) take the one-tile kernel below, which carries 64-bit addresses
+    const unsigned long long in_bytes = (unsigned long long)(a.M / a.HmWm) * a.in_Hp * a.in_Wp * a.in_C * 2ull;
+    if (a.ksteps >= 4 && nbias <= CONV256_MAX_BIAS && tile_ctr && in_bytes < (1ull << 32)) {
         HaloTaps ht;
 #ifdef C256_T_NOHALO9
         if (a.ntaps == 9) {} else          // (same-box A/B only: 3x3 layers on the generic persistent form)

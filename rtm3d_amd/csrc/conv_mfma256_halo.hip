@@ -47,6 +47,7 @@ struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 // recogniser sees them: with the reads hidden in asm instead, the register allocator handed a renamed
 // accumulator's old registers to a ds_read whose data landed before a queued MFMA had read them as SrcC.
 #define DMA16 RT_DMA16                              // common.h: the one LDS-DMA definition
+#define DMA16_SBASE RT_DMA16_SBASE                  // wave-uniform 64-bit base in SGPRs + 32-bit byte offset per lane
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LDS_F32X4(byte_addr) (*(const LDS_AS f32x4*)(uintptr_t)(byte_addr))
 
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     {
         const int rp = wave * 34 + (lane < 34 ? lane : 33);
         const int rhx = rp >> 3, rhcs = rp & 7;
-        roff_e = (uint32_t)(rhx * a.in_C + ((rhcs ^ (rhx & 7)) * 8));             // even halo row: key = hx & 7
-        roff_o = (uint32_t)(rhx * a.in_C + ((rhcs ^ ((rhx ^ 4) & 7)) * 8));       // odd halo row:  key = (hx ^ 4) & 7
+        roff_e = (uint32_t)(rhx * a.in_C + ((rhcs ^ (rhx & 7)) * 8)) * 2u;        // even halo row: key = hx & 7          (BYTES: the
+        roff_o = (uint32_t)(rhx * a.in_C + ((rhcs ^ ((rhx ^ 4) & 7)) * 8)) * 2u;  // odd halo row:  key = (hx ^ 4) & 7     lane offset of DMA16_SBASE)
     }
     const int row_pitch = a.in_Wp * a.in_C;
 
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
         if (rowsl) {
             const int r = sidx < 10 ? sidx : 0;
-            const f16* src = a.in + xb + ch * 64 + (ptrdiff_t)(r * row_pitch) + ((r & 1) ? roff_o : roff_e);
+            const f16* srow = a.in + xb + ch * 64 + (ptrdiff_t)(r * row_pitch);            // wave-uniform: SGPRs
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + (r * 272 + wave * 34) * 8) * 2u);
-            if (xlane_on) DMA16(src, dst);
+            if (xlane_on) DMA16_SBASE((r & 1) ? roff_o : roff_e, srow, dst);
             return;
         }
         const int p0 = ((sidx == NSL ? 0 : sidx) * 8 + wave) * PPW;   // first piece of this wave's run
@@ -165,17 +166,17 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         // LDS position hcs of halo pixel (hy, hx) holds data chunk hcs ^ key, key = (hx ^ (hy << 2)) & 7:
         // consecutive pixels of a row rotate through the banks, and a row step only flips bit 2
         const uint32_t off = (uint32_t)((hy * a.in_Wp + hx) * a.in_C + ((hcs ^ ((hx ^ (hy << 2)) & 7)) * 8));
-        const f16* src = a.in + xb + ch * 64 + off;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + p0 * 8) * 2u);
-        if (xlane_on) DMA16(src, dst);
+        if (xlane_on) DMA16_SBASE(off * 2u, a.in + xb + ch * 64, dst);
     };
     // weight half-tile (0 = WA, 1 = WB) with packed K-tile index kw of weight base wbp into ring buffer par
+    const uint32_t wvoff = (uint32_t)tid * 16u;
     auto stage_w = [&](int half, const f16* wbp, int kw, int par) {
         const f16* ws = wbp + (size_t)kw * (256 * 64) + half * HALF_ELEMS;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((par * 2 + half) * HALF_ELEMS + (i * 512 + wave * 64) * 8) * 2u);
-            DMA16(ws + (i * 512 + tid) * 8, dst);
+            DMA16_SBASE(wvoff, ws + i * 512 * 8, dst);
         }
     };
 
