@@ -40,6 +40,11 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
 #define RT_DMA16_SBASE(voff_bytes, sbase, lds_byte_addr) \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
 
+// the same with the wave's active lanes cut down to `lanemask` (a 64-bit SGPR value) for this one instruction: no branch around it
+#define RT_DMA16_SBASE_LANES(voff_bytes, sbase, lds_byte_addr, lanemask) \
+    { unsigned long long rt_exec_; \
+      asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" \
+                   : "=&s"(rt_exec_) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr), "s"(lanemask) : "memory", "m0", "scc"); }
 #define RT_DMA16_SBASE_NT(voff_bytes, sbase, lds_byte_addr) \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
 

@@ -47,11 +47,12 @@ struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 // recogniser sees them: with the reads hidden in asm instead, the register allocator handed a renamed
 // accumulator's old registers to a ds_read whose data landed before a queued MFMA had read them as SrcC.
 #define DMA16 RT_DMA16                              // common.h: the one LDS-DMA definition
+#define DMA16_SBASE_LANES RT_DMA16_SBASE_LANES
 #define DMA16_SBASE RT_DMA16_SBASE                  // wave-uniform 64-bit base in SGPRs + 32-bit byte offset per lane
 #define LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
 #define LDS_F32X4(byte_addr) (*(const LDS_AS f32x4*)(uintptr_t)(byte_addr))
 
-template <int STATS>
+template <int STATS, int NTAP>          // NTAP: 9 (3 x 3 layers) or 4 (one sub-pixel phase of a 4 x 4 / stride-2 transposed conv)
 __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs a, const HaloTaps ht, const int groups, const int nbias,
                                                                 unsigned int* tile_ctr, float* stat_out) {
     __shared__ __attribute__((aligned(128))) f16 lds[WRING_ELEMS + 2 * HALO_ELEMS];
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave & 1, wc = wave >> 1;
-    const int T = a.ksteps, NTAP = a.ntaps, CPT = a.cpt;
+    const int T = a.ksteps, CPT = a.cpt;
     for (int i = tid; i < nbias; i += 512) lds_bias[i] = a.bias[i];
 
     // tile list (as conv_mfma256_persistent_kernel): position v -> (group, pixel tile, channel tile)
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     // last tap) holds the bottom halo row, first read in P3 of that K-tile: covered.  (With data in the last
     // slot the transposed-conv phases, whose first tap reads the bottom row at once, were not
     // bit-reproducible.)
-    const int NSL = 2 * NTAP - 1;
-    const int PPW = ((HALO_PIECES + 8 * NSL - 1) / (8 * NSL) + 3) & ~3;           // <= 64 for NTAP >= 4
+    constexpr int NSL = 2 * NTAP - 1;
+    constexpr int PPW = ((HALO_PIECES + 8 * NSL - 1) / (8 * NSL) + 3) & ~3;           // <= 64 for NTAP >= 4
     // Round 5, 3x3 layers (NTAP == 9: 18 slots per chunk): a slice is ONE HALO ROW - 34 pixels x 8 pieces = 272 = 8 waves x 34
     // lanes - so a lane's source offset is the same in every slice but for a wave-uniform row offset and the row's parity in
     // the swizzle key (two registers for the whole kernel).  The piece-linear slices above cost ~17 vector instructions per
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     // slots 0 .. 9, the other eight slots re-stage row 0 (same bytes, a buffer nobody reads yet).  The LDS image is unchanged
     // (piece p = row * 272 + pixel * 8 + chunk at p * 16 bytes).  The transposed convs (NTAP == 4: 7 slots < 10 rows) keep
     // the piece-linear slices.
-    const bool rowsl = NTAP == 9;
-    const bool xlane_on = rowsl ? lane < 34 : lane < PPW;
+    constexpr bool rowsl = NTAP == 9;
+    // lanes that take part in a halo-slice DMA (the instruction is issued by every wave, with these lanes only: RT_DMA16_SBASE_LANES)
+    constexpr unsigned long long xlanes = rowsl ? (1ull << 34) - 1 : (PPW >= 64 ? ~0ull : (1ull << PPW) - 1);
     uint32_t roff_e, roff_o;
     {
         const int rp = wave * 34 + (lane < 34 ? lane : 33);
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
     // halo slice s (0 .. 2*NTAP-1) of chunk ch of tile base xb into halo buffer hp
     auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
-        if (rowsl) {
+        if constexpr (rowsl) {
             const int r = sidx < 10 ? sidx : 0;
             const f16* srow = a.in + xb + ch * 64 + (ptrdiff_t)(r * row_pitch);            // wave-uniform: SGPRs
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + (r * 272 + wave * 34) * 8) * 2u);
-            if (xlane_on) DMA16_SBASE((r & 1) ? roff_o : roff_e, srow, dst);
+            DMA16_SBASE_LANES((r & 1) ? roff_o : roff_e, srow, dst, xlanes);
             return;
         }
         const int p0 = ((sidx == NSL ? 0 : sidx) * 8 + wave) * PPW;   // first piece of this wave's run
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         // consecutive pixels of a row rotate through the banks, and a row step only flips bit 2
         const uint32_t off = (uint32_t)((hy * a.in_Wp + hx) * a.in_C + ((hcs ^ ((hx ^ (hy << 2)) & 7)) * 8));
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + p0 * 8) * 2u);
-        if (xlane_on) DMA16_SBASE(off * 2u, a.in + xb + ch * 64, dst);
+        DMA16_SBASE_LANES(off * 2u, a.in + xb + ch * 64, dst, xlanes);
     };
     // weight half-tile (0 = WA, 1 = WB) with packed K-tile index kw of weight base wbp into ring buffer par
     const uint32_t wvoff = (uint32_t)tid * 16u;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
 // Eligibility: every tap within +-1 pixel, stride 1, 8 x 32 tiles cover the output exactly.
 bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
-    if (a.res || a.in_stride != 1 || a.in_P < 1 || a.ntaps > 9 || a.ntaps < 4) return false;
+    if (a.res || a.in_stride != 1 || a.in_P < 1 || (a.ntaps != 9 && a.ntaps != 4)) return false;      // the kernel is instantiated for 9 and 4 taps
     const int nsl = 2 * a.ntaps - 1;
     const int ppw = ((HALO_PIECES + 8 * nsl - 1) / (8 * nsl) + 3) & ~3;
     if (ppw > 64 || 8 * nsl * ppw > HALO_BUF_PIECES) return false;
@@ -518,7 +520,13 @@ hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int 
     stat_out = nullptr;     // (timing only: what do the softmax partials cost their producers?  round 5, same box: 0.504 / 0.510 / 0.513 ms
                             //  with them, 0.467 / 0.475 / 0.486 without = 2.3 us of a 31 us tile, 128 v_exp_f32 per lane)
 #endif
-    if (stat_out) hipLaunchKernelGGL(conv_mfma256_halo_kernel<1>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
-    else hipLaunchKernelGGL(conv_mfma256_halo_kernel<0>, dim3(per_xcd * 8, 1, 1), dim3(512, 1, 1), 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+    const dim3 grid(per_xcd * 8, 1, 1), block(512, 1, 1);
+    if (a.ntaps == 9) {
+        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+    } else if (a.ntaps == 4) {
+        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+    } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
