@@ -30,7 +30,7 @@
 #define HALO_W 34
 #define HALO_PIX (10 * HALO_W)                // 340 pixels
 #define HALO_PIECES (HALO_PIX * 8)            // 2720 16-byte pieces per chunk
-#define HALO_BUF_PIECES 2912                  // buffer size: the (2*ntaps-1) slices x 8 waves x PPW lanes may overrun the halo
+#define HALO_BUF_PIECES 2912                  // buffer size (the halo itself: 2720 pieces)
 #define HALO_ELEMS (HALO_BUF_PIECES * 8)
 #define HALO_MAX_BIAS 1024
 #define H_STAMP_KT 3                          // (diagnostic build -DC256_STAMPS only; the LDS has 1 KB to spare: K-tiles 4..6)
@@ -93,27 +93,21 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const int Hm = a.HmWm / a.Wm;
     const int tiles_x = a.Wm >> 5, tpi = tiles_x * (Hm >> 3);      // 8 x 32 pixel tiles per image
 
-    // halo staging: 2*NTAP - 1 slices per chunk, slice = PPW pieces per wave x 8 waves (16-byte pieces, PPW
-    // rounded up to a multiple of 4 = 64 bytes).  The 2*NTAP-th slot (P3 of the chunk's last tap) re-stages
-    // slice 0: what is issued there may still be in flight when the next chunk's first K-tile reads its
-    // operands (a read in phase p is covered by the wait of phase p-1, which lets the DMA of the four
-    // phases before it stay pending), so it must not carry anything new.  The last real slice (P2 of the
-    // last tap) holds the bottom halo row, first read in P3 of that K-tile: covered.  (With data in the last
-    // slot the transposed-conv phases, whose first tap reads the bottom row at once, were not
-    // bit-reproducible.)
-    constexpr int NSL = 2 * NTAP - 1;
-    constexpr int PPW = ((HALO_PIECES + 8 * NSL - 1) / (8 * NSL) + 3) & ~3;           // <= 64 for NTAP >= 4
-    // Round 5, 3x3 layers (NTAP == 9: 18 slots per chunk): a slice is ONE HALO ROW - 34 pixels x 8 pieces = 272 = 8 waves x 34
-    // lanes - so a lane's source offset is the same in every slice but for a wave-uniform row offset and the row's parity in
-    // the swizzle key (two registers for the whole kernel).  The piece-linear slices above cost ~17 vector instructions per
-    // slice (a division by 34 among them) in the load segments of phases 2 and 3, which is what the partner wave's MFMA
-    // segment waits for (in-kernel stamps: 380 / 410 cycles against 200 / 305 in the generic kernel).  Rows 0 .. 9 ride in
-    // slots 0 .. 9, the other eight slots re-stage row 0 (same bytes, a buffer nobody reads yet).  The LDS image is unchanged
-    // (piece p = row * 272 + pixel * 8 + chunk at p * 16 bytes).  The transposed convs (NTAP == 4: 7 slots < 10 rows) keep
-    // the piece-linear slices.
-    constexpr bool rowsl = NTAP == 9;
-    // lanes that take part in a halo-slice DMA (the instruction is issued by every wave, with these lanes only: RT_DMA16_SBASE_LANES)
-    constexpr unsigned long long xlanes = rowsl ? (1ull << 34) - 1 : (PPW >= 64 ? ~0ull : (1ull << PPW) - 1);
+    // Halo staging.  The halo of the NEXT chunk (10 rows x 34 pixels x 64 channels) is staged one ROW per DMA instruction - 34 pixels
+    // x 8 pieces = 272 = 8 waves x 34 lanes - while the current chunk's taps are multiplied: a lane's source offset is the same in
+    // every row but for the row's parity in the swizzle key (roff_e / roff_o, two registers for the whole kernel), and the row itself
+    // is a wave-uniform cursor in SGPRs (xs_src, xs_dst) that moves one row per instruction, beside the MFMAs of the segment
+    // that follows.  LDS image: piece p = row * 272 + pixel * 8 + chunk at p * 16 bytes.
+    //   NTAP == 9: two rows per K-tile (phases 2 and 3): rows 0 .. 9 in taps 0 .. 4, then the cursor swings between rows 8 and 9
+    //              (same bytes again) - the instruction count per K-tile must not change, the counted waits are immediates;
+    //   NTAP == 4: three rows per K-tile (phases 2, 3 and 4): rows 0 .. 8 in taps 0 .. 2, then 9, 8, 7.
+    // What the last K-tile of a chunk issues may still be in flight when the next chunk's first K-tile reads its operands (a read
+    // in phase p is covered by the wait of phase p-1, which lets the DMA of the four phases before it stay pending), so it must
+    // not carry anything new beyond phase 2, whose row - the bottom one - is first read in phase 3 of that K-tile: covered.
+    // (History: piece-linear slices, 2*NTAP-1 per chunk, ~17 vector instructions each with a division by 34, in the load segments
+    // of phases 2 and 3 - which is what the partner wave's MFMA segment waits for; round 5: rows for the 3x3 layers, -2.3 %; then the
+    // row address itself as a running cursor instead of ~25 scalar instructions per slice, and rows for the transposed convs too.)
+    constexpr unsigned long long xlanes = (1ull << 34) - 1;       // lanes of a row DMA (issued by every wave: RT_DMA16_SBASE_LANES)
     uint32_t roff_e, roff_o;
     {
         const int rp = wave * 34 + (lane < 34 ? lane : 33);
@@ -121,13 +115,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         roff_e = (uint32_t)(rhx * a.in_C + ((rhcs ^ (rhx & 7)) * 8)) * 2u;        // even halo row: key = hx & 7          (BYTES: the
         roff_o = (uint32_t)(rhx * a.in_C + ((rhcs ^ ((rhx ^ 4) & 7)) * 8)) * 2u;  // odd halo row:  key = (hx ^ 4) & 7     lane offset of DMA16_SBASE)
     }
-    const int row_pitch = a.in_Wp * a.in_C;
-
     // tile descriptors (current / next): halo origin in the input tensor, weight base, indices
-    size_t xb_c, xb_n;                      // element offset of halo pixel (0,0), channel 0 of the group slice
+    const char *xb_c, *xb_n;                // halo pixel (0,0), channel 0 of the group slice
     const f16 *wb_c, *wb_n;
     int gi_c, gi_n, nt_c, nt_n, n_c, n_n, ty_c, ty_n, tx_c, tx_n;
-    auto locate = [&](int vv, size_t& xb, const f16*& wb, int& gi, int& nt, int& n, int& ty, int& tx) {
+    auto locate = [&](int vv, const char*& xb, const f16*& wb, int& gi, int& nt, int& n, int& ty, int& tx) {
         // (group-major order.  Round 5, same-box A/B: the four sub-pixel phases of a transposed conv - which read the SAME input
         // halo - on consecutive tickets instead, so that three of four halo fetches hit L2: no change, 0.507 vs 0.506 ms, although
         // these launches fetch their input 4-5 times over, 0.63 GB against 0.13 GB: the fabric traffic is not what they wait for.)
@@ -141,40 +133,32 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         ty = r / tiles_x;
         tx = r - ty * tiles_x;
         const ConvGroupArgs& g = a.g[gi];
-        xb = ((size_t)(n * a.in_Hp + ty * 8 - 1 + a.in_P) * a.in_Wp + tx * 32 - 1 + a.in_P) * a.in_C + g.in_coff;
+        xb = (const char*)(a.in + ((size_t)(n * a.in_Hp + ty * 8 - 1 + a.in_P) * a.in_Wp + tx * 32 - 1 + a.in_P) * a.in_C + g.in_coff);
         wb = a.wgt + g.w_off + (size_t)nt * T * (256 * 64);
     };
     bool live_n = false;
     locate(v, xb_c, wb_c, gi_c, nt_c, n_c, ty_c, tx_c);
     xb_n = xb_c; wb_n = wb_c; gi_n = gi_c; nt_n = nt_c; n_n = n_c; ty_n = ty_c; tx_n = tx_c;
 
-    // halo slice s (0 .. 2*NTAP-1) of chunk ch of tile base xb into halo buffer hp
-    auto stage_x = [&](int sidx, size_t xb, int ch, int hp) {
-        if constexpr (rowsl) {
-            const int r = sidx < 10 ? sidx : 0;
-            const f16* srow = a.in + xb + ch * 64 + (ptrdiff_t)(r * row_pitch);            // wave-uniform: SGPRs
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + (r * 272 + wave * 34) * 8) * 2u);
-            DMA16_SBASE_LANES((r & 1) ? roff_o : roff_e, srow, dst, xlanes);
-            return;
-        }
-        const int p0 = ((sidx == NSL ? 0 : sidx) * 8 + wave) * PPW;   // first piece of this wave's run
-        // Every wave issues this instruction with its first PPW lanes in every call - a wave that skipped
-        // it would count one DMA less than vmcnt(6) assumes and read a weight tile before it has landed.
-        // Pieces past the halo re-read its last piece into the slack at the end of the buffer.
-        int p = p0 + lane;
-        p = p < HALO_PIECES ? p : HALO_PIECES - 1;
-        const int hq = p >> 3, hcs = p & 7;
-        const int hy = hq / HALO_W, hx = hq - hy * HALO_W;
-        // LDS position hcs of halo pixel (hy, hx) holds data chunk hcs ^ key, key = (hx ^ (hy << 2)) & 7:
-        // consecutive pixels of a row rotate through the banks, and a row step only flips bit 2
-        const uint32_t off = (uint32_t)((hy * a.in_Wp + hx) * a.in_C + ((hcs ^ ((hx ^ (hy << 2)) & 7)) * 8));
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + p0 * 8) * 2u);
-        DMA16_SBASE_LANES(off * 2u, a.in + xb + ch * 64, dst, xlanes);
+    const ptrdiff_t pitch_b = (ptrdiff_t)a.in_Wp * a.in_C * 2;     // one halo row down, in bytes
+    constexpr int ROW_LDS_B = 272 * 16;
+    const char* xs_src;
+    uint32_t xs_dst;
+    // cursor to row 0 of chunk ch of the tile at xb, into halo buffer hp
+    auto xs_reset = [&](const char* xb, int ch, int hp) {
+        xs_src = xb + ch * 128;
+        xs_dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + wave * 34 * 8) * 2u);
     };
-    // weight half-tile (0 = WA, 1 = WB) with packed K-tile index kw of weight base wbp into ring buffer par
+    auto xs_issue = [&](uint32_t roff) { DMA16_SBASE_LANES(roff, xs_src, xs_dst, xlanes); };
+    auto xs_move = [&](bool down) {
+        xs_src += down ? pitch_b : -pitch_b;
+        xs_dst += down ? (uint32_t)ROW_LDS_B : (uint32_t)-ROW_LDS_B;
+    };
+
+    // weight half-tile (0 = WA, 1 = WB) of the packed K-tile at wk into ring buffer par
     const uint32_t wvoff = (uint32_t)tid * 16u;
-    auto stage_w = [&](int half, const f16* wbp, int kw, int par) {
-        const f16* ws = wbp + (size_t)kw * (256 * 64) + half * HALF_ELEMS;
+    auto stage_w = [&](int half, const f16* wk, int par) {
+        const f16* ws = wk + half * HALF_ELEMS;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((par * 2 + half) * HALF_ELEMS + (i * 512 + wave * 64) * 8) * 2u);
@@ -198,13 +182,12 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     const f16x4 lo4 = {lo, lo, lo, lo};
 
     // ---- prologue (once per workgroup): halo of chunk 0, WA(0), WB(0), WA(1), WB(1); everything lands
-    for (int sidx = 0; sidx < 2 * NTAP; ++sidx) stage_x(sidx, xb_c, 0, 0);
-    stage_w(0, wb_c, 0, 0);
-    stage_w(1, wb_c, 0, 0);
-    stage_w(0, wb_c, CPT, 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
-#ifndef HALO_WB_IN_P1
-    stage_w(1, wb_c, CPT, 1);
-#endif
+    xs_reset(xb_c, 0, 0);
+    for (int r = 0; r < 10; ++r) { xs_issue((r & 1) ? roff_o : roff_e); xs_move(true); }
+    stage_w(0, wb_c, 0);
+    stage_w(1, wb_c, 0);
+    stage_w(0, wb_c + (size_t)CPT * (256 * 64), 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
+    stage_w(1, wb_c + (size_t)CPT * (256 * 64), 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
@@ -289,16 +272,25 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 // phase 1 of the K-tile before (behind 12 operand reads): its target half was last read in phase 2, and with six DMA
 // instructions per K-tile either way the counted waits retire every half-tile at the same barrier as before.  Same box, round 5,
 // three interleaved rounds: heads.conv_d1 3.665 / 3.702 / 3.669 -> 3.558 / 3.549 / 3.561 ms, fusion_up5.2 0.510 -> 0.500,
-// kfpn_up3 0.468 -> 0.471 (-DHALO_WB_IN_P1 restores the old order for A/Bs).  The halo slices do not follow: the second slice beside
+// kfpn_up3 0.468 -> 0.471.  The halo slices do not follow: the second slice beside
 // the first in phase 2 (phase 3 then only reads) 3.51 -> 3.72 ms, both slices in phase 4 (all six DMAs in the read-free segment,
 // phases 1-3 only read) 3.51 -> 3.57 and fusion_up5.2 0.50 -> 0.56 - one slice behind the reads of phases 2 and 3 each stays.
-#ifdef HALO_WB_IN_P1
-#define STAGE_WB_P1 stage_w(1, ch1 == CPT ? wb_n : wb_c, tap1 * CPT + (ch1 == CPT ? 0 : ch1), sp ^ 1);
-#define STAGE_WB_P4
-#else
-#define STAGE_WB_P1
-#define STAGE_WB_P4 stage_w(1, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);
-#endif
+// The halo-row cursor (xs_src, xs_dst) moves in the load segment, between the segment's operand reads and its row DMA: scalar
+// instructions only, which run while the reads are in flight.  (Same box, round 5, heads.conv_d1: the same instructions beside the
+// MFMAs of the segment before 3.37 -> 3.51 ms - a wave issues in order, and scalar work between its MFMAs opens bubbles in a pipe
+// that is busy 16 cycles out of 16; the row DMA itself moved beside the MFMAs 3.61; behind an explicit wait for the reads 3.52.)
+// xr_a / xr_b: the lane offsets (row parity) of the K-tile's rows.
+#define XS_TO_ROW_A     /* straight-line on purpose: a branch splits the block and the scheduler's fences with it */ \
+    {                                                                                           \
+        const char* rs_ = (xn ? xb_n : xb_c) + (xn ? 0 : ch + 1) * 128;                         \
+        const uint32_t rd_ = lds_base + (uint32_t)(WRING_ELEMS + (hpar ^ 1) * HALO_ELEMS + wave * 34 * 8) * 2u; \
+        xs_move(NTAP == 9 ? tap <= 4 : true);                   /* from the last row of the K-tile before */ \
+        xs_src = tap == 0 ? rs_ : xs_src; xs_dst = tap == 0 ? rd_ : xs_dst;                     \
+        if constexpr (NTAP == 4) { xr_a = (tap & 1) ? roff_o : roff_e; xr_b = (tap & 1) ? roff_e : roff_o; } \
+    }
+#define XS_TO_ROW_B xs_move(NTAP == 9 ? true : tap != 3);
+#define XS_TO_ROW_C xs_move(tap != 3);
+#define WS_HOOK ws_p = (ch2 >= CPT ? wb_n : wb_c) + (size_t)(tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2)) * (256 * 64);
 #define STEP_H(VM, FIRST, LAST)                                                                 \
     {                                                                                           \
         const uint32_t wbuf = lds_base + (uint32_t)sp * (2 * HALF_ELEMS * 2);                    \
@@ -310,19 +302,22 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         const bool xn = ch + 1 == CPT;               /* the halo staged now is the next tile's chunk 0 */ \
         LOAD_X_H(0)                                                                             \
         LOAD_W_H(wa, 0)                                                                         \
-        STAGE_WB_P1                                                                             \
         SEG_SYNC_H(VM, 0)                                                                       \
         MMA_H(0, 0, wa, FIRST, 1, 0)                                                            \
         LOAD_W_H(wb, 1)                                                                         \
-        stage_x(2 * tap, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                           \
+        XS_TO_ROW_A                                                                             \
+        xs_issue(xr_a);                                                                         \
         SEG_SYNC_H(VM, 5)                                                                       \
         MMA_H(0, 1, wb, FIRST, 1, 5)                                                            \
         LOAD_X_H(1)                                                                             \
-        stage_x(2 * tap + 1, xn ? xb_n : xb_c, xn ? 0 : ch + 1, hpar ^ 1);                       \
+        XS_TO_ROW_B                                                                             \
+        xs_issue(xr_b);                                                                         \
         SEG_SYNC_H(VM, 10)                                                                      \
         MMA_H(1, 1, wb, FIRST, 1, 10)                                                           \
-        stage_w(0, ch2 >= CPT ? wb_n : wb_c, tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2), sp);   \
-        STAGE_WB_P4                                                                             \
+        WS_HOOK                                                                                 \
+        stage_w(0, ws_p, sp);                                                                   \
+        stage_w(1, ws_p, sp);                                                                   \
+        if constexpr (NTAP == 4) { XS_TO_ROW_C xs_issue(xr_a); }                                \
         SEG_SYNC_H(VM, 15)                                                                      \
         MMA_HX(1, 0, wa, FIRST, !(LAST), 15, HALO_XADDR_NEXT, HALO_XADDR_PIN)                   \
         HSTAMP_NEXT                                                                             \
@@ -331,6 +326,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     }
 
     uint32_t xu_c, xw_c;                    // this lane's pixel-operand fragment addresses of the NEXT K-tile to run (HALO_XADDR_NEXT)
+    uint32_t xr_a = roff_e, xr_b = roff_o;
+    const f16* ws_p = wb_c;
     HALO_XADDR(ht.taps[gi_c], 0, 0, xu_c, xw_c)
     for (;;) {
         // ticket of the tile after next (see conv_mfma256_persistent_kernel)
@@ -356,16 +353,18 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                     for (int p = 0; p < 4; ++p) acc[i][j][cc][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned long long tapword = ht.taps[gi_c];
         int ch = 0, tap = 0;
-        STEP_H(22, 1, 0)                    // 6 + the previous tile's 16 stores
+        // (the counted waits are immediates: 6 DMA instructions per K-tile with nine taps, 7 with four)
+        if constexpr (NTAP == 9) STEP_H(22, 1, 0) else STEP_H(23, 1, 0)                    // + the previous tile's 16 stores
         if (wave == 0) {
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(ticket) : : "memory");   // the atomic is older than this K-tile's 6 DMAs
+            if constexpr (NTAP == 9) asm volatile("s_waitcnt vmcnt(6)" : "+v"(ticket) : : "memory");   // the atomic is older than this K-tile's DMAs
+            else asm volatile("s_waitcnt vmcnt(7)" : "+v"(ticket) : : "memory");
             if (lane == 0) {
                 lds_ticket[tpar] = ticket;
                 if (draw && ticket == last_draw) tile_ctr[xcd] = 0u;
             }
         }
-        for (int kt = 1; kt < T - 1; ++kt) STEP_H(6, 0, 0)
-        STEP_H(6, 0, 1)
+        for (int kt = 1; kt < T - 1; ++kt) { if constexpr (NTAP == 9) STEP_H(6, 0, 0) else STEP_H(7, 0, 0) }
+        if constexpr (NTAP == 9) STEP_H(6, 0, 1) else STEP_H(7, 0, 1)
         // last MFMA segment had no trailing barrier: waves 0-3 take it before their epilogue, waves 4-7 after
         if (wave < 4) __builtin_amdgcn_s_barrier();
 
@@ -493,9 +492,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 // Eligibility: every tap within +-1 pixel, stride 1, 8 x 32 tiles cover the output exactly.
 bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
     if (a.res || a.in_stride != 1 || a.in_P < 1 || (a.ntaps != 9 && a.ntaps != 4)) return false;      // the kernel is instantiated for 9 and 4 taps
-    const int nsl = 2 * a.ntaps - 1;
-    const int ppw = ((HALO_PIECES + 8 * nsl - 1) / (8 * nsl) + 3) & ~3;
-    if (ppw > 64 || 8 * nsl * ppw > HALO_BUF_PIECES) return false;
     if (a.Wm % 32 || (a.HmWm / a.Wm) % 8 || a.M % a.HmWm) return false;
     const int pitch = a.in_Wp * a.in_C;
     for (int g = 0; g < RT_MAX_GROUPS; ++g) ht->taps[g] = 0;
