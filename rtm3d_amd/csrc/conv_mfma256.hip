@@ -339,7 +339,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // -DC256_WB_IN_P4 - phase 4 of the K-tile before that (no operand reads there; legal with the same counted waits: its target
 // half was last read in phase 2).  Same box, round 5: the halo kernel gains 3 % from the move (heads.conv_d1 3.64 -> 3.54 ms),
 // this kernel loses 0.7 % (heads.conv_d6 3.547 -> 3.572, backbone 2.31 -> 2.33): here phase 4 already carries the tap-table
-// lookup and every phase stages two DMAs, so the move only unbalances them.  Kept in phase 1.
+// lookup and every phase stages two DMAs, so the move only unbalances them.  Kept in phase 1.  (Likewise XA from phase 3 into
+// phase 4 - legal with the same counted wait: heads.conv_d6 3.49 -> 3.57, the level-4 convs +2.5 %.)
 #ifndef C256_WB_IN_P4
 #define STAGE_WB_P1 stage(SLOT_WB, t + 1, sp ^ 1, 0);
 #define STAGE_WB_P4
