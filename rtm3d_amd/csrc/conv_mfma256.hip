@@ -553,14 +553,21 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
             asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
                          : "=&v"(ticket), "=&s"(saved_exec) : "v"(off), "v"(inc), "s"(tile_ctr) : "memory");
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+        // the accumulators start at the bias (fp32, from LDS) instead of at zero: the epilogue then has no add (64 packed adds per
+        // lane and tile less, in the one part of a tile that no MFMA overlaps)
+        {
+            const float* bp = lds_bias + a.g[gi_c].bias_off + nt_c * 256 + wc * 32 + fk * 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 b4 = *(const f32x4*)(bp + j * 128 + c * 16);
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[i][j][c][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[i][j][c][p] = b4;
+                }
+        }
         int t = 0;
         TSTAMP(0)
         // The first K-tile's waits count the previous tile's 16 stores as well.  The workgroup's FIRST tile has none before it: with
@@ -589,14 +596,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         {
             const ConvGroupArgs& g = a.g[gi_c];
             const int cbase = g.out_coff + nt_c * 256 + wc * 32 + so;
-            f32x4 bv[2][2];
-            {
-                const float* bp = lds_bias + g.bias_off + nt_c * 256 + wc * 32 + fk * 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) bv[j][c] = *(const f32x4*)(bp + j * 128 + c * 16);
-            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 size_t opix[4];
@@ -626,7 +625,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
                         uint32_t u[2][2];
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            f32x4 vv = acc[i][j][c][p] + bv[j][c];       // same order as the other conv kernels
+                            f32x4 vv = acc[i][j][c][p];                  // (bias: the accumulators started at it)
                             if (RES) {
                                 const f16x4 r = rv[p][j][c];
                                 vv[0] += (float)r[0]; vv[1] += (float)r[1]; vv[2] += (float)r[2]; vv[3] += (float)r[3];

@@ -343,14 +343,21 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         // halo during the last chunk - which is the first K-tile already when cin = 64
         live_n = draw;
         if (live_n) locate(vnext, xb_n, wb_n, gi_n, nt_n, n_n, ty_n, tx_n);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+        // the accumulators start at the bias (fp32, from LDS) instead of at zero: the epilogue then has no add (64 packed adds per
+        // lane and tile less, in the one part of a tile that no MFMA overlaps)
+        {
+            const float* bp = lds_bias + a.g[gi_c].bias_off + nt_c * 256 + wc * 32 + fk * 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+                for (int cc = 0; cc < 2; ++cc) {
+                    const f32x4 b4 = *(const f32x4*)(bp + j * 128 + cc * 16);
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[i][j][cc][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[i][j][cc][p] = b4;
+                }
+        }
         const unsigned long long tapword = ht.taps[gi_c];
         int ch = 0, tap = 0;
         // (the counted waits are immediates: 6 DMA instructions per K-tile with nine taps, 7 with four)
@@ -372,14 +379,6 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         {
             const ConvGroupArgs& g = a.g[gi_c];
             const int cbase = g.out_coff + nt_c * 256 + wc * 32 + so_ch;
-            f32x4 bv[2][2];
-            {
-                const float* bp = lds_bias + g.bias_off + nt_c * 256 + wc * 32 + fk * 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) bv[j][cc] = *(const f32x4*)(bp + j * 128 + cc * 16);
-            }
             f16x4 hq[2][4][2][2];          // fp16 results [pixel half][pixel tile][channel half][channel tile]
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                         uint32_t u[2][2];
 #pragma unroll
                         for (int cc = 0; cc < 2; ++cc) {
-                            const f32x4 vv = acc[i][j][cc][p] + bv[j][cc];
+                            const f32x4 vv = acc[i][j][cc][p];                      // (bias: the accumulators started at it)
                             f16x4 h = {(f16)vv[0], (f16)vv[1], (f16)vv[2], (f16)vv[3]};
                             h = __builtin_elementwise_max(h, lo4);
                             if (STATS) hq[i][p][j][cc] = h;
