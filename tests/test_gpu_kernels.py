@@ -124,6 +124,30 @@ def test_halo_conv256_vs_torch(shape):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
 
 
+def test_conv256_input_beyond_4gb():
+    """The persistent 256 x 256 kernel addresses its pixel operand as an SGPR base + a 32-bit byte offset per lane (round 5): a conv
+    whose input tensor is 4 GB or larger must not run on it (launch_conv_mfma256 sends it to the one-tile kernel, which carries
+    64-bit addresses).  Input = the last 256 channels of an 8 x 96 x 320 x 8704-channel tensor (4.39 GB; the last image lies beyond
+    4 GB): wrapped offsets would read other images' pixels - still inside the allocation, so a wrong routing shows as a mismatch."""
+    B, H, W, cin, cout, extra = 8, 96, 320, 256, 256, 8448
+    rng = np.random.default_rng(11)
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt = P.tensor(H, W, cin + extra, 1)
+    xs = P.sub(xt, extra, cin)
+    yt = P.tensor(H, W, cout, 1)
+    ys = P.sub(yt, 0, cout)
+    assert B * (H + 2) * (W + 2) * (cin + extra) * 2 >= 1 << 32
+    w = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    P.conv(xs, ys, w, b, relu=True, name='t')
+    P.ops[-1]['variant'] = 2
+    # every image different, so that reading image (n - 7.8) instead of image n cannot go unnoticed
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    (got,), _ = _run(P, [(xs, x)], [ys])
+    ref = h(F.conv2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), torch.from_numpy(b)).relu()).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
 def test_split_k_chain_is_deterministic():
     """Two split-K convolutions back to back share the slab and the per-tile arrival counters (the last workgroup of a
     tile re-arms its counter): the chain must match torch, carry the expected kernels, and replay bit-identically."""
