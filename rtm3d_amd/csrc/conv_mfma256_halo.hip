@@ -242,8 +242,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     __builtin_amdgcn_sched_barrier(0);                                                          \
     HSTAMP((K0) + 4)
 // LDS addresses of this lane's pixel-operand fragments for tap `tp` of the halo in buffer hp (xu / xw: the two k-half slots of an
-// even halo row; LOAD_X_H swaps them on odd rows).  Round 5: computed beside the MFMAs of phase 4 for the NEXT K-tile (six
-// full-rate vector instructions that fit the MFMA gaps) instead of at the head of phase 1's load segment, whose reads wait for them.
+// even halo row; LOAD_X_H swaps them on odd rows).  Round 5: computed a K-tile AHEAD, in phase 4's load segment - the one without
+// operand reads - instead of at the head of phase 1's, whose reads wait for them.  (First placed beside the MFMAs of phase 4, with a
+// scalar load and a branch for the next tile's tap word: heads.conv_d1 3.336 -> 3.28 ms, transposed convs -1 %, from moving them out
+// of the MFMA segment and keeping both tap words in SGPRs for the tile.)
 #define HALO_XADDR(TW, TP, HP, XU, XW)                                                          \
     {                                                                                           \
         const uint32_t hb_ = lds_base + (uint32_t)(WRING_ELEMS + (HP) * HALO_ELEMS) * 2;          \
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     {                                                                                           \
         int tapn_ = tap + 1, hparn_ = hpar;                                                     \
         unsigned long long twn_ = tapword;                                                      \
-        if (tapn_ == NTAP) { tapn_ = 0; hparn_ ^= 1; if (ch + 1 == CPT) twn_ = ht.taps[gi_n]; }  \
+        if (tapn_ == NTAP) { tapn_ = 0; hparn_ ^= 1; if (ch + 1 == CPT) twn_ = tapword_n; }     \
         HALO_XADDR(twn_, tapn_, hparn_, xu_c, xw_c)                                             \
     }
 #define HALO_XADDR_PIN asm volatile("" : "+v"(xu_c), "+v"(xw_c));
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         stage_w(0, ws_p, sp);                                                                   \
         stage_w(1, ws_p, sp);                                                                   \
         if constexpr (NTAP == 4) { XS_TO_ROW_C xs_issue(xr_a); }                                \
+        HALO_XADDR_NEXT HALO_XADDR_PIN   /* phase 4's load segment has no operand reads: the next K-tile's fragment addresses */ \
         SEG_SYNC_H(VM, 15)                                                                      \
-        MMA_HX(1, 0, wa, FIRST, !(LAST), 15, HALO_XADDR_NEXT, HALO_XADDR_PIN)                   \
+        MMA_H(1, 0, wa, FIRST, !(LAST), 15)                                                     \
         HSTAMP_NEXT                                                                             \
         sp ^= 1;                                                                                \
         if (++tap == NTAP) { tap = 0; ++ch; hpar ^= 1; }                                         \
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
                         for (int p = 0; p < 4; ++p) acc[i][j][cc][p] = b4;
                 }
         }
-        const unsigned long long tapword = ht.taps[gi_c];
+        const unsigned long long tapword = ht.taps[gi_c], tapword_n = ht.taps[gi_n];     // (both in SGPRs for the whole tile: no load, no branch in the K loop)
         int ch = 0, tap = 0;
         // (the counted waits are immediates: 6 DMA instructions per K-tile with nine taps, 7 with four)
         if constexpr (NTAP == 9) STEP_H(22, 1, 0) else STEP_H(23, 1, 0)                    // + the previous tile's 16 stores
