@@ -147,7 +147,10 @@ def header_forward(z, sd, prefix='detect_header'):
     for seq, last in HEADS:
         p = '%s.%s' % (prefix, seq)
         h = F.relu(_bn(_conv(z, sd, p + '.0', 1, 6, 6), sd, p + '.1'))    # conv3x3 d6 p6 + bias, BN, ReLU
-        h = F.relu(_bn(_conv(h, sd, p + '.3', 1, 1, 1), sd, p + '.4'))    # conv3x3 d1 p1 + bias, BN, ReLU
+        k = 1                                                             # HEADER_NUM_CONV - 1 further levels (header.py:12: dilation [6] + [1] * (n - 1);
+        while '%s.%d.weight' % (p, 3 * k) in sd:                          #  make_conv_level numbers them 3k, 3k + 1, 3k + 2 in the Sequential)
+            h = F.relu(_bn(_conv(h, sd, '%s.%d' % (p, 3 * k), 1, 1, 1), sd, '%s.%d' % (p, 3 * k + 1)))   # conv3x3 d1 p1 + bias, BN, ReLU
+            k += 1
         outs.append(_conv(h, sd, '%s.%s' % (p, last), 1, 1, 1))           # conv3x3 p1 -> C_out + bias
     return tuple(outs)
 

@@ -55,8 +55,12 @@ class Model(object):
         self.config = config
         self._backbone_name = backbone if isinstance(backbone, str) else config.MODEL.BACKBONE
         parse_backbone(self._backbone_name)
-        if int(config.MODEL.OUT_CHANNELS) != 256 or int(config.MODEL.HEADER_NUM_CONV) != 2:
-            raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256, HEADER_NUM_CONV=2')
+        if int(config.MODEL.OUT_CHANNELS) != 256:
+            raise NotImplementedError('the HIP kernels are built for OUT_CHANNELS=256 (both shipped configs), got %r' % (config.MODEL.OUT_CHANNELS,))
+        # MODEL.HEADER_NUM_CONV (models/nets/header.py:12-13): one dilation-6 conv + (n - 1) dilation-1 convs per branch; any n >= 1
+        self._num_conv = int(config.MODEL.HEADER_NUM_CONV)
+        if self._num_conv < 1:
+            raise ValueError('MODEL.HEADER_NUM_CONV must be >= 1, got %r' % (config.MODEL.HEADER_NUM_CONV,))
         # MODEL.KFNs names the backbone outputs the neck fuses (models/nets/keypoint_fpn_fusion.py:11-17).  The plan is built for
         # the four outputs every shipped config names; anything else is refused HERE instead of being silently ignored.  (The
         # reference itself only runs with all four, in order: its backbones always return four maps and KeypointFPNFusion._fpn
@@ -82,7 +86,7 @@ class Model(object):
         self.use_graph = None                    # None: automatic (hipGraph replay for batches <= GRAPH_MAX_BATCH)
         # reference-style initial weights (utils/torch_utils.py:71-83); replaced by load_state_dict
         self._sd = synth_state_dict(self._backbone_name, seed=0, style='init', head_variant=self._head_variant,
-                                    num_classes=self._num_classes)
+                                    num_classes=self._num_classes, header_num_conv=self._num_conv)
         self.backbone = _Namespace(self, 'backbone')
         self.kfpn_fusion = _Namespace(self, 'kfpn_fusion')
         self.detect_header = _Namespace(self, 'detect_header')
@@ -92,7 +96,7 @@ class Model(object):
         return OrderedDict(self._sd)
 
     def load_state_dict(self, state_dict, strict=True):
-        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name, self._head_variant, self._num_classes))
+        want = OrderedDict((k, shape) for k, shape, _, _ in state_dict_spec(self._backbone_name, self._head_variant, self._num_classes, self._num_conv))
         missing = [k for k in want if k not in state_dict]
         unexpected = [k for k in state_dict if k not in want]
         if strict and (missing or unexpected):
@@ -168,7 +172,8 @@ class Model(object):
             if self._wcache is None:
                 self._wcache = WeightCache(self._sd)
             ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache,
-                                     num_classes=self._num_classes, dense_heads=1 if heads == 'peaks' else None)
+                                     num_classes=self._num_classes, dense_heads=1 if heads == 'peaks' else None,
+                                     header_num_conv=self._num_conv)
             with torch.cuda.device(device):
                 p = plan_mod.RealizedPlan(ir, device.index)
                 # small batches are bound by launch gaps, not by the kernels: replay those plans as one hipGraph
@@ -267,7 +272,7 @@ class Model(object):
             if self._wcache is None:
                 self._wcache = WeightCache(self._sd)
             ir = plan_mod.build_plan(self._sd, self._backbone_name, B, H, W, self._head_variant, cache=self._wcache,
-                                     num_classes=self._num_classes)
+                                     num_classes=self._num_classes, header_num_conv=self._num_conv)
             self._verify = (key, VerifyPlanF32(ir, x.device))
         return self._verify[1].forward(x, self._head_channels)
 
@@ -308,6 +313,9 @@ class Model(object):
         same stream).  Same Detections as decode2d on the dense logits, vertices to fp16 round-off of the network.
         from_forward: when heat_logits is an edited COPY of what forward_logits returned (tests plant peaks), the original
         tuple - the freshness check below is made on it."""
+        if self._num_conv != 2:
+            # the patch plan's windows (15 -> 5 -> 3 -> 1) are the receptive field of d6 + d1 + the logit conv, plan.build_peak_plan
+            raise NotImplementedError('peaks-only regression heads are built for MODEL.HEADER_NUM_CONV = 2 (got %d): use the dense heads' % self._num_conv)
         hm = heat_logits[0] if isinstance(heat_logits, (tuple, list)) else heat_logits
         hm_src = hm if from_forward is None else (from_forward[0] if isinstance(from_forward, (tuple, list)) else from_forward)
         B, _, Hm, Wm = hm.shape

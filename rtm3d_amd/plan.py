@@ -320,14 +320,14 @@ def _build_resnet(P, sd, H, W, depth, feat_out):
             inpl = pl
 
 
-def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None, num_classes=3, dense_heads=None):
+def build_plan(state_dict, backbone, B, H, W, head_variant='rtm3d', cache=None, num_classes=3, dense_heads=None, header_num_conv=2):
     """state_dict: reference key names -> torch tensors.  H, W multiples of 32.  cache: a WeightCache of this state dict.
     dense_heads = k: only the first k head branches are evaluated on the whole map (1 = the heat map alone: the other
     branches then come from build_peak_plan at the detected peaks)."""
     global _CACHE
     _CACHE = cache
     try:
-        P = _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes, dense_heads)
+        P = _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes, dense_heads, header_num_conv)
     finally:
         _CACHE = None
     P.cache = cache
@@ -379,7 +379,7 @@ def build_peak_plan(state_dict, slots, map_hw, head_variant='rtm3d', cache=None,
     return P
 
 
-def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3, dense_heads=None):
+def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3, dense_heads=None, header_num_conv=2):
     kind, depth = parse_backbone(backbone)
     if H % 32 or W % 32:
         raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
@@ -452,15 +452,24 @@ def _build_plan(state_dict, backbone, B, H, W, head_variant, num_classes=3, dens
     G = len(heads)
     # (op names key the packed-weight cache: a plan with fewer dense branches packs other arrays under other names)
     hn = 'heads' if dense_heads is None else 'heads[:%d]' % G
+    # MODEL.HEADER_NUM_CONV (header.py:12-13): one dilation-6 conv, then HEADER_NUM_CONV - 1 dilation-1 convs per branch (the shipped
+    # configs: 2), as Sequential indices 3k / 3k + 1 of make_conv_level (utils/torch_utils.py:179-204).  The d1 convs ping-pong
+    # between the two 4 x 256-channel tensors.
+    nconv = int(header_num_conv)
+    if nconv < 1:
+        raise ValueError('MODEL.HEADER_NUM_CONV must be >= 1, got %r' % (header_num_conv,))
     h1 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h1')
-    h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2')
+    h2 = P.tensor(fh[0][0], fh[0][1], G * oc, 1, name='h2') if nconv > 1 else None
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.0' % seq, 'detect_header.%s.1' % seq) for seq, _, _ in heads])
     P.conv(z, h1, np.concatenate(ws, 0), np.concatenate(bs, 0), dil=6, relu=True, name=hn + '.conv_d6')
-    ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.3' % seq, 'detect_header.%s.4' % seq) for seq, _, _ in heads])
-    P.grouped_conv([P.sub(h1, g * oc, oc) for g in range(G)], [P.sub(h2, g * oc, oc) for g in range(G)], ws, bs,
-                   relu=True, name=hn + '.conv_d1')
+    src, dst = h1, h2
+    for k in range(1, nconv):
+        ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%d' % (seq, 3 * k), 'detect_header.%s.%d' % (seq, 3 * k + 1)) for seq, _, _ in heads])
+        P.grouped_conv([P.sub(src, g * oc, oc) for g in range(G)], [P.sub(dst, g * oc, oc) for g in range(G)], ws, bs,
+                       relu=True, name=hn + ('.conv_d1' if k == 1 else '.conv_d1_%d' % k))
+        src, dst = dst, src
     ws, bs = zip(*[fold_bn(sd, 'detect_header.%s.%s' % (seq, last)) for seq, last, _ in heads])
-    P.headout(h2, ws, bs, name=hn + '.out_convs')
+    P.headout(src, ws, bs, name=hn + '.out_convs')
     P.head_channels = [c for _, _, c in heads]
     return P
 

@@ -15,6 +15,7 @@ There is no network access for the published checkpoints, so benchmarks and test
   sparse (a handful of detections per image) and activations stay O(1) in fp16.
 """
 import math
+import re
 from collections import OrderedDict
 
 import numpy as np
@@ -102,7 +103,7 @@ def _dla_tree_spec(s, p, level, cin, cout, stride, level_root, root_dim=0):
         s.bn(p + '.project.1', cout)
 
 
-def state_dict_spec(backbone, head_variant='rtm3d', num_classes=3):
+def state_dict_spec(backbone, head_variant='rtm3d', num_classes=3, header_num_conv=2):
     """Ordered [(key, shape, kind, meta)] identical to the reference ``state_dict()`` order."""
     kind, depth = parse_backbone(backbone)
     s = _Spec()
@@ -148,10 +149,10 @@ def state_dict_spec(backbone, head_variant='rtm3d', num_classes=3):
     # models/nets/header.py:13-37
     for seq, last, cout in head_table(head_variant, num_classes):
         p = 'detect_header.' + seq
-        s.conv(p + '.0', oc, oc, 3, bias=True)
-        s.bn(p + '.1', oc)
-        s.conv(p + '.3', oc, oc, 3, bias=True)
-        s.bn(p + '.4', oc)
+        # make_conv_level (utils/torch_utils.py:179-204): HEADER_NUM_CONV x (conv, BN, ReLU) = Sequential indices 3k, 3k + 1, (3k + 2)
+        for k in range(int(header_num_conv)):
+            s.conv('%s.%d' % (p, 3 * k), oc, oc, 3, bias=True)
+            s.bn('%s.%d' % (p, 3 * k + 1), oc)
         s.conv('%s.%s' % (p, last), cout, oc, 3, bias=True)
     return s.items
 
@@ -182,7 +183,7 @@ def _trained_gain(bkind, key):
     if key.startswith('detect_header'):
         if key.endswith('.0.weight'):
             return g['h0']
-        if key.endswith('.3.weight'):
+        if re.search(r'\.(3|6|9|12)\.weight$', key):       # the dilation-1 convs of the branch (HEADER_NUM_CONV - 1 of them)
             return g['h3']
         return g['head']
     if key.endswith('conv2.weight'):
@@ -190,7 +191,7 @@ def _trained_gain(bkind, key):
     return g['conv']
 
 
-def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d', heat_gain=1.0, num_classes=3):
+def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_variant='rtm3d', heat_gain=1.0, num_classes=3, header_num_conv=2):
     """Deterministic synthetic weights (fp32 CPU tensors) under the reference key names.
     ``heat_gain`` scales the last heat-map conv ("trained" style only): > 1 spreads the peak scores over a wider
     range, as a trained detector's are, instead of the narrow band random features give."""
@@ -199,7 +200,7 @@ def synth_state_dict(backbone, seed=0, style='trained', heat_bias=-6.0, head_var
     bkind = parse_backbone(backbone)[0]
     sd = OrderedDict()
     bil = _bilinear_kernel(4)
-    for key, shape, kind, meta in state_dict_spec(backbone, head_variant, num_classes):
+    for key, shape, kind, meta in state_dict_spec(backbone, head_variant, num_classes, header_num_conv):
         if kind == 'conv':
             cout, cin, k, _ = shape
             fan_in, fan_out = cin * k * k, cout * k * k

@@ -55,14 +55,14 @@ assert torch.backends.cpu.get_cpu_capability() == 'AVX512', \
     'golden vectors must be generated on an AVX-512 host (got %s)' % torch.backends.cpu.get_cpu_capability()
 
 
-def make_cfg(backbone, thresh=0.4, topk=100):
-    return NS(MODEL=NS(BACKBONE=backbone, DOWN_SAMPLE=4., OUT_CHANNELS=256, KFNs=KFNS[backbone], HEADER_NUM_CONV=2),
+def make_cfg(backbone, thresh=0.4, topk=100, nconv=2):
+    return NS(MODEL=NS(BACKBONE=backbone, DOWN_SAMPLE=4., OUT_CHANNELS=256, KFNs=KFNS[backbone], HEADER_NUM_CONV=nconv),
               DATASET=NS(OBJs=['Car', 'Pedestrian', 'Cyclist'], VERTEX_OFFSET_INFER=[0.75, 0.57]),
               DETECTOR=NS(SCORE_THRESH=thresh, TOPK_CANDIDATES=topk))
 
 
-def ref_model(backbone, sd, thresh=0.4, topk=100):
-    cfg = make_cfg(backbone, thresh, topk)
+def ref_model(backbone, sd, thresh=0.4, topk=100, nconv=2):
+    cfg = make_cfg(backbone, thresh, topk, nconv)
     bb = dla.create_model(cfg) if 'DLA' in backbone else resnet.get_pose_net(backbone.split('-')[-1], cfg)
     m = Model(cfg, bb).eval()
     if sd is not None:
@@ -131,30 +131,36 @@ def decode3d_to_arrays(dets, K, prefix, out):
 
 # (backbone, seed, heat_bias, heat_gain, B, H, W, tag): heat_gain/heat_bias chosen so that each image has ~20-30
 # detections whose scores spread over 0.4 .. 0.95 (random features alone give a narrow band of peak heights)
+NC1_HB, NC1_HG, NC3_HB, NC3_HG = -6.75, 3.5, -12.4, 3.5
 E2E_CASES = [('DLA-34', 1, -16.9, 3.5, 2, 128, 256, 'small'), ('RESNET-18', 1, -22.8, 6.0, 2, 128, 256, 'small'),
              ('RESNET-34', 1, -14.3, 4.0, 2, 128, 256, 'small'),
              ('DLA-34', 1, -25.0, 4.5, 1, 384, 1280, 'full'), ('RESNET-18', 1, -30.0, 6.5, 1, 384, 1280, 'full'),
              # the real-KITTI letterbox shape: with IS_RECT the reference pads 1242 x 375 images to 1280 x 416 (datasets/dataset_reader.py:55-61):
              # level4 / level5 maps of 26 x 80 / 13 x 40 (H % 8 != 0 there: the 8 x 32 halo-tile kernels are not eligible)
-             ('DLA-34', 1, -25.0, 4.5, 1, 416, 1280, 'kitti416'), ('RESNET-18', 1, -29.2, 6.5, 1, 416, 1280, 'kitti416')]
+             ('DLA-34', 1, -25.0, 4.5, 1, 416, 1280, 'kitti416'), ('RESNET-18', 1, -29.2, 6.5, 1, 416, 1280, 'kitti416'),
+             # MODEL.HEADER_NUM_CONV other than the shipped 2 (models/nets/header.py:12-13: [6] + [1] * (n - 1) dilations): 1 and 3
+             ('DLA-34', 1, NC1_HB, NC1_HG, 2, 128, 256, 'small_nc1', 1), ('DLA-34', 1, NC3_HB, NC3_HG, 2, 128, 256, 'small_nc3', 3)]
 
 
 def gen_e2e(only_tag=None):
-    for bb, seed, hb, hg, B, H, W, tag in E2E_CASES:
+    for case in E2E_CASES:
+        bb, seed, hb, hg, B, H, W, tag = case[:8]
+        nconv = case[8] if len(case) > 8 else 2
         if only_tag is not None and tag != only_tag:
             continue
-        sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb, heat_gain=hg)
-        m = ref_model(bb, sd)
+        sd = weights.synth_state_dict(bb, seed, 'trained', heat_bias=hb, heat_gain=hg, header_num_conv=nconv)
+        m = ref_model(bb, sd, nconv=nconv)
         x = weights.synth_images(B, H, W, seed=1234)
         with torch.no_grad():
             dets, logits = m(x)
         assert_tie_free(logits[0], 100)
         out = {'backbone': bb, 'seed': seed, 'heat_bias': hb, 'heat_gain': hg, 'style': 'trained', 'shape': np.array([B, H, W]),
+               'header_num_conv': nconv,
                'img_seed': 1234,
                # guards against drift of the numpy bit-stream that regenerates weights/images on another box
                'w_probe': sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1].copy(),
                'x_probe': x[0, :, :2, :8].numpy().copy()}
-        if tag == 'small':
+        if tag.startswith('small'):
             for i, name in enumerate(['main_kf', 'offset_fr_main', 'main_offset', 'vertex_offset']):
                 out['logits_' + name] = logits[i].numpy()
         else:

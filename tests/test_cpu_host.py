@@ -169,11 +169,24 @@ def test_unsupported_config_is_refused_loudly():
     c.MODEL.BACKBONE = 'RESNET-18'
     with pytest.raises(NotImplementedError, match='KFNs'):
         rtm3d_amd.create_model(c)
-    for key, val in (('OUT_CHANNELS', 128), ('HEADER_NUM_CONV', 3)):
+    c = rtm3d_amd.kitti_config('DLA-34')
+    c.MODEL.OUT_CHANNELS = 128
+    with pytest.raises(NotImplementedError, match='OUT_CHANNELS'):
+        rtm3d_amd.create_model(c)
+    # HEADER_NUM_CONV is a real parameter since round 5 (one dilation-6 conv + n - 1 dilation-1 convs per branch, header.py:12-13):
+    # the state-dict surface follows it under the reference's Sequential indices 3k / 3k + 1; 0 is refused
+    for n, keys in ((1, 321 - 4 * 7), (2, 321), (3, 321 + 4 * 7)):       # conv weight + bias, BN weight / bias / mean / var / count
         c = rtm3d_amd.kitti_config('DLA-34')
-        c.MODEL[key] = val
-        with pytest.raises(NotImplementedError, match='OUT_CHANNELS'):
-            rtm3d_amd.create_model(c)
+        c.MODEL.HEADER_NUM_CONV = n
+        sd = rtm3d_amd.create_model(c).state_dict()
+        assert len(sd) == keys, (n, len(sd))
+        assert ('detect_header.main_offset_header.%d.weight' % (3 * (n - 1))) in sd
+        assert ('detect_header.main_offset_header.%d.weight' % (3 * n)) not in sd
+        assert tuple(sd['detect_header.main_offset_header.main_offset_head.weight'].shape) == (2, 256, 3, 3)
+    c = rtm3d_amd.kitti_config('DLA-34')
+    c.MODEL.HEADER_NUM_CONV = 0
+    with pytest.raises(ValueError, match='HEADER_NUM_CONV'):
+        rtm3d_amd.create_model(c)
 
 
 def test_state_dict_surface_and_checkpoint(tmp_path):

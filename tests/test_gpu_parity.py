@@ -45,9 +45,10 @@ def dev():
     return torch.device('cuda', 0)
 
 
-def make_model(bb, sd=None, thresh=0.4, topk=100):
+def make_model(bb, sd=None, thresh=0.4, topk=100, nconv=2):
     cfg = rtm3d_amd.kitti_config(bb)
     cfg.DETECTOR.SCORE_THRESH, cfg.DETECTOR.TOPK_CANDIDATES = thresh, topk
+    cfg.MODEL.HEADER_NUM_CONV = nconv
     m = rtm3d_amd.create_model(cfg).to('cuda:0').eval()
     if sd is not None:
         m.load_state_dict(sd)
@@ -264,16 +265,20 @@ def _rel_err(got, ref):
 # fp32 verification mode, peaks-only regression heads)
 E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz',
        'e2e_dla34_kitti416.npz', 'e2e_resnet18_kitti416.npz']
+# MODEL.HEADER_NUM_CONV = 1 and 3 (models/nets/header.py:12-13: one dilation-6 conv + n - 1 dilation-1 convs per branch), reference-run
+E2E_NC = ['e2e_dla34_small_nc1.npz', 'e2e_dla34_small_nc3.npz']
 
 
-@pytest.mark.parametrize('fname', E2E)
+@pytest.mark.parametrize('fname', E2E + E2E_NC)
 def test_forward_logits_vs_reference_golden(dev, fname):
     g = load_golden(fname)
     bb = str(g['backbone'])
     B, H, W = [int(v) for v in g['shape']]
-    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
+    nconv = int(g['header_num_conv']) if 'header_num_conv' in g else 2
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']),
+                                  header_num_conv=nconv)
     x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
-    m = make_model(bb, sd)
+    m = make_model(bb, sd, nconv=nconv)
     (clses, scores, mprojs, verts, boxes), logits = m(x.to(dev))
     ref0 = g['logits_main_kf']
     tol = HM_RTOL * max(1.0, np.abs(ref0).max())
@@ -314,6 +319,15 @@ def test_forward_logits_vs_reference_golden(dev, fname):
                                                                      'vertex_linf_px': vmax})
     assert vmax < VERT_TOL_PX, vmax
     assert checked >= 12 * B, checked       # the fixtures bite: ~20 detections per image with scores 0.4 .. 0.95
+
+
+def test_sparse_heads_refuse_other_header_depths(dev):
+    """The peaks-only regression heads are a patch plan of exactly d6 + d1 + logit conv (plan.build_peak_plan): with
+    MODEL.HEADER_NUM_CONV = 3 the call surface says so instead of evaluating the wrong receptive field."""
+    m = make_model('DLA-34', weights.synth_state_dict('DLA-34', 1, 'trained', header_num_conv=3), nconv=3)
+    x = weights.synth_images(1, 64, 128, seed=3).to(dev)
+    with pytest.raises(NotImplementedError, match='HEADER_NUM_CONV'):
+        m.detect(x)
 
 
 @pytest.mark.parametrize('fname', E2E)
@@ -1355,7 +1369,7 @@ FP32_LOGIT_RTOL = 2e-5          # |logit - reference fp32 CPU logit| / max(1, ma
 FP32_VERT_TOL_PX = 2e-3
 
 
-@pytest.mark.parametrize('fname', E2E)
+@pytest.mark.parametrize('fname', E2E + E2E_NC)
 def test_fp32_verify_logits_vs_reference_golden(dev, fname):
     """The verification executor reproduces the reference's fp32 CPU logits to fp32 round-off on every e2e fixture
     (three backbones, two sizes) - i.e. the recorded plan (graph wiring, BN folding, phases, composed 1x1s) is the
@@ -1363,9 +1377,11 @@ def test_fp32_verify_logits_vs_reference_golden(dev, fname):
     g = load_golden(fname)
     bb = str(g['backbone'])
     B, H, W = [int(v) for v in g['shape']]
-    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
+    nconv = int(g['header_num_conv']) if 'header_num_conv' in g else 2
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']),
+                                  header_num_conv=nconv)
     x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
-    m = make_model(bb, sd)
+    m = make_model(bb, sd, nconv=nconv)
     logits = m.forward_logits_fp32(x.to(dev))
     errs = {'main_kf': _rel_err(logits[0].cpu().numpy(), g['logits_main_kf'])}
     for i, name in enumerate(['offset_fr_main', 'main_offset', 'vertex_offset'], 1):

@@ -12,14 +12,17 @@ from tests.util import load_golden, dets_from_golden, to_np, canon_dets
 
 E2E = ['e2e_dla34_small.npz', 'e2e_resnet18_small.npz', 'e2e_resnet34_small.npz', 'e2e_dla34_full.npz', 'e2e_resnet18_full.npz',
        'e2e_dla34_kitti416.npz', 'e2e_resnet18_kitti416.npz']
+# MODEL.HEADER_NUM_CONV = 1 and 3 (models/nets/header.py:12-13), run through the reference like the others
+E2E_NC = ['e2e_dla34_small_nc1.npz', 'e2e_dla34_small_nc3.npz']
 
 
-@pytest.mark.parametrize('fname', E2E)
+@pytest.mark.parametrize('fname', E2E + E2E_NC)
 def test_oracle_forward_matches_reference(fname):
     g = load_golden(fname)
     bb = str(g['backbone'])
     B, H, W = [int(v) for v in g['shape']]
-    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']))
+    sd = weights.synth_state_dict(bb, int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']),
+                                  header_num_conv=int(g['header_num_conv']) if 'header_num_conv' in g else 2)
     x = weights.synth_images(B, H, W, seed=int(g['img_seed']))
     # the seeded generators must reproduce the tensors the reference was run on
     np.testing.assert_array_equal(sd['detect_header.main_kf_header.main_kf_head.weight'].numpy()[:, :4, 1, 1], g['w_probe'])
