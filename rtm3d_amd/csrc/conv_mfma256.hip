@@ -348,11 +348,15 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 #define STAGE_WB_P1
 #define STAGE_WB_P4 stage(SLOT_WB, t + 2, sp, 0);
 #endif
+#define OPA_SET(SP)                                                                         \
+    {                                                                                       \
+        const uint32_t bufb_ = lds_base + (uint32_t)(SP) * (BUF_ELEMS * 2);                 \
+        opa[0] = bufb_ + xrow_b0; opa[1] = bufb_ + xrow_b1; opa[2] = bufb_ + wrow_b0; opa[3] = bufb_ + wrow_b1; \
+    }
 #define STEP_N(VM, FIRST, LAST)                                                             \
     {                                                                                       \
-        const uint32_t bufb = lds_base + (uint32_t)sp * (BUF_ELEMS * 2);                    \
-        const uint32_t xaddr0 = bufb + xrow_b0, xaddr1 = bufb + xrow_b1;                    \
-        const uint32_t waddr0 = bufb + wrow_b0, waddr1 = bufb + wrow_b1;                    \
+        /* this lane's operand addresses in the K-tile's buffer: computed a K-tile ahead, in phase 4's load segment (no operand reads there) */ \
+        const uint32_t xaddr0 = opa[0], xaddr1 = opa[1], waddr0 = opa[2], waddr1 = opa[3];  \
         LOAD_X_N(SLOT_XA)                                                                   \
         LOAD_W_N(wa, SLOT_WA)                                                               \
         STAGE_WB_P1                                                                         \
@@ -371,6 +375,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
         int kchan3;                                                                         \
         int kraw3 = koff_parts(t + 3, kchan3);                                              \
         stage(SLOT_WA, t + 2, sp, 0);                                                       \
+        OPA_SET(sp ^ 1)                                                                     \
+        asm volatile("" : "+v"(opa[0]), "+v"(opa[1]), "+v"(opa[2]), "+v"(opa[3]));          \
         STAGE_WB_P4                                                                         \
         SEG_SYNC_S(VM, 15)                                                                  \
         asm volatile("" : "+s"(kraw3));           /* first use of the loaded word: behind the segment's wait */ \
@@ -538,6 +544,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     int tpar = 0;
     int koff1 = koff_of(1), koff2 = koff_of(2);           // T >= 4: both inside the first tile
     bool first_tile = true;
+    uint32_t opa[4];
+    OPA_SET(0)
 
     for (;;) {
         // draw the ticket of the tile after next (unless the last draw already came back empty); it is
