@@ -206,8 +206,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     }
 #define LOAD_W_H(dstf, HALF)                                                                    \
     _Pragma("unroll") for (int cc = 0; cc < 2; ++cc) {                                          \
-        dstf[cc][0] = LDS_F16X8(wbuf + wrow_b0 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
-        dstf[cc][1] = LDS_F16X8(wbuf + wrow_b1 + (HALF) * HALF_ELEMS * 2 + cc * 2048);          \
+        dstf[cc][0] = LDS_F16X8(wad0 + (HALF) * HALF_ELEMS * 2 + cc * 2048);                    \
+        dstf[cc][1] = LDS_F16X8(wad1 + (HALF) * HALF_ELEMS * 2 + cc * 2048);                    \
     }
 // Diagnostic build only (-DC256_STAMPS, see conv_mfma256.hip): s_memtime stamps of waves 0 and 4 in the K loop of the second tile.
 #ifdef C256_STAMPS
@@ -293,9 +293,10 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 #define XS_TO_ROW_B xs_move(NTAP == 9 ? true : tap != 3);
 #define XS_TO_ROW_C xs_move(tap != 3);
 #define WS_HOOK ws_p = (ch2 >= CPT ? wb_n : wb_c) + (size_t)(tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2)) * (256 * 64);
+#define WAD_SET(SP) { const uint32_t wb_ = lds_base + (uint32_t)(SP) * (2 * HALF_ELEMS * 2); wad_c[0] = wb_ + wrow_b0; wad_c[1] = wb_ + wrow_b1; }
 #define STEP_H(VM, FIRST, LAST)                                                                 \
     {                                                                                           \
-        const uint32_t wbuf = lds_base + (uint32_t)sp * (2 * HALF_ELEMS * 2);                    \
+        const uint32_t wad0 = wad_c[0], wad1 = wad_c[1];   /* weight-operand addresses in ring buffer sp: computed a K-tile ahead (phase 4) */ \
         HALO_XADDR_NOW                                                                          \
         int tap1 = tap + 1, ch1 = ch;                                                           \
         if (tap1 == NTAP) { tap1 = 0; ch1 = ch + 1; }                                            \
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         stage_w(0, ws_p, sp);                                                                   \
         stage_w(1, ws_p, sp);                                                                   \
         if constexpr (NTAP == 4) { XS_TO_ROW_C xs_issue(xr_a); }                                \
+        WAD_SET(sp ^ 1) asm volatile("" : "+v"(wad_c[0]), "+v"(wad_c[1]));                      \
         HALO_XADDR_NEXT HALO_XADDR_PIN   /* phase 4's load segment has no operand reads: the next K-tile's fragment addresses */ \
         SEG_SYNC_H(VM, 15)                                                                      \
         MMA_H(1, 0, wa, FIRST, !(LAST), 15)                                                     \
@@ -330,6 +332,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
     uint32_t xu_c, xw_c;                    // this lane's pixel-operand fragment addresses of the NEXT K-tile to run (HALO_XADDR_NEXT)
     uint32_t xr_a = roff_e, xr_b = roff_o;
+    uint32_t wad_c[2];
+    WAD_SET(0)
     const f16* ws_p = wb_c;
     HALO_XADDR(ht.taps[gi_c], 0, 0, xu_c, xw_c)
     for (;;) {
