@@ -209,7 +209,8 @@ def test_persistent_conv_replays_identically():
         np.testing.assert_array_equal(got, outs[0])
 
 
-@pytest.mark.parametrize('shape', [(2, 6, 10, 0), (1, 12, 40, 0), (4, 24, 80, 2), (32, 12, 40, 2)])
+# (the last two: maps covered by 8 x 32 tiles - the four sub-pixel phases run on the halo-tile kernel, three halo rows per K-tile)
+@pytest.mark.parametrize('shape', [(2, 6, 10, 0), (1, 12, 40, 0), (4, 24, 80, 2), (32, 12, 40, 2), (2, 16, 64, 2), (5, 24, 96, 2)])
 def test_deconv_phases_vs_torch(shape):
     B, H, W, variant = shape
     rng = np.random.default_rng(B * 1000 + H)
