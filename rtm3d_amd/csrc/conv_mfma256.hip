@@ -340,7 +340,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // half was last read in phase 2).  Same box, round 5: the halo kernel gains 3 % from the move (heads.conv_d1 3.64 -> 3.54 ms),
 // this kernel loses 0.7 % (heads.conv_d6 3.547 -> 3.572, backbone 2.31 -> 2.33): here phase 4 already carries the tap-table
 // lookup and every phase stages two DMAs, so the move only unbalances them.  Kept in phase 1.  (Likewise XA from phase 3 into
-// phase 4 - legal with the same counted wait: heads.conv_d6 3.49 -> 3.57, the level-4 convs +2.5 %.)
+// phase 4 - legal with the same counted wait: heads.conv_d6 3.49 -> 3.57, the level-4 convs +2.5 %; WB behind XB in phase 2, with
+// phase 1's wait tightened to vmcnt(4): 3.380 -> 3.391, the folded 96 x 320 neck conv +1.5 %.)
 #ifndef C256_WB_IN_P4
 #define STAGE_WB_P1 stage(SLOT_WB, t + 1, sp ^ 1, 0);
 #define STAGE_WB_P4
