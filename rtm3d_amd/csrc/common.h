@@ -36,17 +36,25 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp_d) {
 // non-temporal form (single-read streams)
 #define RT_DMA16_NT(gptr, lds_byte_addr) \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gptr), "s"(lds_byte_addr) : "memory", "m0")
-// wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane (no 64-bit address registers)
+// wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane (no 64-bit address registers).  The base goes through
+// rt_uniform_ptr: where the compiler already holds it in SGPRs that is no instruction at all; where its divergence analysis lost
+// track (seen in the -DC256_STAMPS build) it becomes two v_readfirstlane instead of a VGPR pair in an "s" operand, which the assembler
+// rejects.
+static __device__ __forceinline__ const void* rt_uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
 #define RT_DMA16_SBASE(voff_bytes, sbase, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(rt_uniform_ptr(sbase)), "s"(lds_byte_addr) : "memory", "m0")
 
 // the same with the wave's active lanes cut down to `lanemask` (a 64-bit SGPR value) for this one instruction: no branch around it
 #define RT_DMA16_SBASE_LANES(voff_bytes, sbase, lds_byte_addr, lanemask) \
     { unsigned long long rt_exec_; \
       asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" \
-                   : "=&s"(rt_exec_) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr), "s"(lanemask) : "memory", "m0", "scc"); }
+                   : "=&s"(rt_exec_) : "v"(voff_bytes), "s"(rt_uniform_ptr(sbase)), "s"(lds_byte_addr), "s"(lanemask) : "memory", "m0", "scc"); }
 #define RT_DMA16_SBASE_NT(voff_bytes, sbase, lds_byte_addr) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0")
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff_bytes), "s"(rt_uniform_ptr(sbase)), "s"(lds_byte_addr) : "memory", "m0")
 
 #define RT_MAX_GROUPS 4
 #define RT_MAX_TAPS 80
