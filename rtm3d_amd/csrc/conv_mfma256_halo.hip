@@ -15,7 +15,7 @@
 // Differences: the weight ring holds only WA/WB half-tiles (64 KB); the halo of the NEXT chunk (or of the
 // next tile's first chunk) is staged in 2*ntaps-1 equal slices, one DMA instruction per wave in each P2 and
 // P3 (<= 64 lanes active, source address computed on the fly from the slice index), so that every K-tile
-// issues the same 0+1+1+4 DMA instructions (P4: WA and WB of K-tile kt+2) and the counted s_waitcnt stays an immediate (vmcnt(6)).
+// issues the same 0+2+2+2 DMA instructions (P2 / P3: a halo row + half of WA, P4: WB, of K-tile kt+2) and the counted s_waitcnt stays an immediate (vmcnt(6)).
 // When there is no next tile the same instructions re-stage data of the current tile into ring slots
 // that are already free: no dummy slot (the LDS is full) and no run-time counts.  (First version: six
 // 512-lane halo DMAs on taps 0-2 and per-phase counts dispatched through a switch: the scalar code of
@@ -157,6 +157,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 
     // weight half-tile (0 = WA, 1 = WB) of the packed K-tile at wk into ring buffer par
     const uint32_t wvoff = (uint32_t)tid * 16u;
+    // one of the two DMA instructions (i = 0, 1) of a weight half-tile
+    auto stage_w1 = [&](int half, int i, const f16* wk, int par) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((par * 2 + half) * HALF_ELEMS + (i * 512 + wave * 64) * 8) * 2u);
+        DMA16_SBASE(wvoff, wk + half * HALF_ELEMS + i * 512 * 8, dst);
+    };
     auto stage_w = [&](int half, const f16* wk, int par) {
         const f16* ws = wk + half * HALF_ELEMS;
 #pragma unroll
@@ -293,6 +298,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
 #define XS_TO_ROW_B xs_move(NTAP == 9 ? true : tap != 3);
 #define XS_TO_ROW_C xs_move(tap != 3);
 #define WS_HOOK ws_p = (ch2 >= CPT ? wb_n : wb_c) + (size_t)(tap2 * CPT + (ch2 >= CPT ? ch2 - CPT : ch2)) * (256 * 64);
+// The four weight DMA instructions of K-tile kt+2 are spread two per phase with the halo rows: WA's behind the row DMAs of phases 2
+// and 3, WB's in phase 4 (every target half was last read two or more phases earlier; six - seven with four taps - instructions
+// per K-tile as before, so the counted waits retire each half-tile at the same barrier as before).  In-kernel stamps of the form
+// with all four in phase 4 (profiles/r05_c256_stamps_final.txt): load segments 204 / 158 / 60 / 352 cycles against a 256-cycle MFMA
+// segment of the partner wave.  Same box, three rounds: heads.conv_d1 3.208 -> 3.164 ms, the transposed convs 0.455 -> 0.446.
+#define WSPLIT_P2 WS_HOOK stage_w1(0, 0, ws_p, sp);
+#define WSPLIT_P3 stage_w1(0, 1, ws_p, sp);
+#define WSPLIT_P4 stage_w(1, ws_p, sp);
 #define WAD_SET(SP) { const uint32_t wb_ = lds_base + (uint32_t)(SP) * (2 * HALF_ELEMS * 2); wad_c[0] = wb_ + wrow_b0; wad_c[1] = wb_ + wrow_b1; }
 #define STEP_H(VM, FIRST, LAST)                                                                 \
     {                                                                                           \
@@ -310,16 +323,16 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         LOAD_W_H(wb, 1)                                                                         \
         XS_TO_ROW_A                                                                             \
         xs_issue(xr_a);                                                                         \
+        WSPLIT_P2                                                                               \
         SEG_SYNC_H(VM, 5)                                                                       \
         MMA_H(0, 1, wb, FIRST, 1, 5)                                                            \
         LOAD_X_H(1)                                                                             \
         XS_TO_ROW_B                                                                             \
         xs_issue(xr_b);                                                                         \
+        WSPLIT_P3                                                                               \
         SEG_SYNC_H(VM, 10)                                                                      \
         MMA_H(1, 1, wb, FIRST, 1, 10)                                                           \
-        WS_HOOK                                                                                 \
-        stage_w(0, ws_p, sp);                                                                   \
-        stage_w(1, ws_p, sp);                                                                   \
+        WSPLIT_P4                                                                               \
         if constexpr (NTAP == 4) { XS_TO_ROW_C xs_issue(xr_a); }                                \
         WAD_SET(sp ^ 1) asm volatile("" : "+v"(wad_c[0]), "+v"(wad_c[1]));                      \
         HALO_XADDR_NEXT HALO_XADDR_PIN   /* phase 4's load segment has no operand reads: the next K-tile's fragment addresses */ \
