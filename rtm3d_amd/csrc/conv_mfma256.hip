@@ -342,29 +342,41 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // lookup and every phase stages two DMAs, so the move only unbalances them.  Kept in phase 1.  (Likewise XA from phase 3 into
 // phase 4 - legal with the same counted wait: heads.conv_d6 3.49 -> 3.57, the level-4 convs +2.5 %; WB behind XB in phase 2, with
 // phase 1's wait tightened to vmcnt(4): 3.380 -> 3.391, the folded 96 x 320 neck conv +1.5 %.)
-#ifndef C256_WB_IN_P4
-#define STAGE_WB_P1 stage(SLOT_WB, t + 1, sp ^ 1, 0);
+// Round 5, after the stamps of the final form (profiles/r05_c256_stamps_final.txt: load segments 346 / 170 / 205 / 255 cycles against the
+// partner wave's 256-cycle MFMA segment): WB's two DMA instructions are split - one stays behind phase 1's twelve reads, the other
+// goes behind XB in phase 2, the lightest segment.  Phase 1's wait is then vmcnt(5) (the five youngest: its own WB instruction,
+// WA x 2, XA x 2), which retires XB and both halves of WB one barrier before their first read, as before; the other three
+// waits stay vmcnt(8).  Same box, three rounds: heads.conv_d6 3.430 -> 3.394 ms.
+#if !defined(C256_WB_IN_P4)
+#define STAGE_WB_P1 stage_w1(SLOT_WB, 0, t + 1, sp ^ 1);
+#define STAGE_WB_P2 stage_w1(SLOT_WB, 1, t + 1, sp ^ 1);
 #define STAGE_WB_P4
+#define VM1_8 5
+#define VM1_24 21
 #else
 #define STAGE_WB_P1
+#define STAGE_WB_P2
 #define STAGE_WB_P4 stage(SLOT_WB, t + 2, sp, 0);
+#define VM1_8 8
+#define VM1_24 24
 #endif
 #define OPA_SET(SP)                                                                         \
     {                                                                                       \
         const uint32_t bufb_ = lds_base + (uint32_t)(SP) * (BUF_ELEMS * 2);                 \
         opa[0] = bufb_ + xrow_b0; opa[1] = bufb_ + xrow_b1; opa[2] = bufb_ + wrow_b0; opa[3] = bufb_ + wrow_b1; \
     }
-#define STEP_N(VM, FIRST, LAST)                                                             \
+#define STEP_N(VM, VM1, FIRST, LAST)                                                          \
     {                                                                                       \
         /* this lane's operand addresses in the K-tile's buffer: computed a K-tile ahead, in phase 4's load segment (no operand reads there) */ \
         const uint32_t xaddr0 = opa[0], xaddr1 = opa[1], waddr0 = opa[2], waddr1 = opa[3];  \
         LOAD_X_N(SLOT_XA)                                                                   \
         LOAD_W_N(wa, SLOT_WA)                                                               \
         STAGE_WB_P1                                                                         \
-        SEG_SYNC_S(VM, 0)                                                                   \
+        SEG_SYNC_S(VM1, 0)                                                                  \
         MMA_S(0, 0, wa, FIRST, 1, 0)                                                        \
         LOAD_W_N(wb, SLOT_WB)                                                               \
         stage(SLOT_XB, t + 1, sp ^ 1, koff1);                                               \
+        STAGE_WB_P2                                                                         \
         SEG_SYNC_S(VM, 5)                                                                   \
         MMA_S(0, 1, wb, FIRST, 1, 5)                                                        \
         LOAD_X_N(SLOT_XB)                                                                   \
@@ -491,6 +503,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     // 64-bit vector address arithmetic in the load segments (round 5: two to four VALU instructions per DMA before, two of them
     // 64-bit adds).  The launcher keeps tensors past 4 GB off this kernel.
     const uint32_t wvoff = (uint32_t)tid * 16u;
+    // one of the two DMA instructions (i = 0, 1) of weight half-tile `slot` (SLOT_WA / SLOT_WB) of K-tile position kpos
+    auto stage_w1 = [&](int slot, int i, int kpos, int par) {
+        const bool in_cur = kpos < T;
+        const int k = in_cur ? kpos : kpos - T;
+        const uint32_t dst0 = lds_base + (uint32_t)((in_cur || live_n) ? par * BUF_ELEMS + slot * HALF_ELEMS : 2 * BUF_ELEMS) * 2u;
+        const f16* ws = (in_cur ? wb_c : wb_n) + (size_t)k * (256 * 64) + (slot - 2) * HALF_ELEMS;
+        DMA16_SBASE(wvoff, ws + i * 512 * 8, __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)((i * 512 + wave * 64) * 16)));
+    };
     auto stage = [&](int slot, int kpos, int par, int koff) {
         const bool in_cur = kpos < T;
         const int k = in_cur ? kpos : kpos - T;
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         TSTAMP(0)
         // The first K-tile's waits count the previous tile's 16 stores as well.  The workgroup's FIRST tile has none before it: with
         // the same count its waits would let the prologue's K-tile-1 half-tiles stay in flight past their first read.
-        if (first_tile) STEP_N(8, 1, 0) else STEP_N(24, 1, 0)
+        if (first_tile) STEP_N(8, VM1_8, 1, 0) else STEP_N(24, VM1_24, 1, 0)
         first_tile = false;
         if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(ticket) : : "memory");
@@ -593,8 +613,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
         // successor tile: its first half-tiles are staged from K-tile T-2 of this one
         live_n = draw;
         if (live_n) locate(vnext, xo_n, wb_n, gi_n, mt_n, nt_n);
-        for (t = 1; t < T - 1; ++t) STEP_N(8, 0, 0)
-        STEP_N(8, 0, 1)
+        for (t = 1; t < T - 1; ++t) STEP_N(8, VM1_8, 0, 0)
+        STEP_N(8, VM1_8, 0, 1)
         // The last MFMA segment has no trailing barrier.  Waves 0-3 take it here, before their
         // epilogue, waves 4-7 (one barrier behind) after theirs: otherwise each group would sit at a
         // barrier for the whole of the other group's epilogue (measured: 2 x 2.8 us per tile).
