@@ -346,7 +346,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // partner wave's 256-cycle MFMA segment): WB's two DMA instructions are split - one stays behind phase 1's twelve reads, the other
 // goes behind XB in phase 2, the lightest segment.  Phase 1's wait is then vmcnt(5) (the five youngest: its own WB instruction,
 // WA x 2, XA x 2), which retires XB and both halves of WB one barrier before their first read, as before; the other three
-// waits stay vmcnt(8).  Same box, three rounds: heads.conv_d6 3.430 -> 3.394 ms.
+// waits stay vmcnt(8).  Same box, three rounds: heads.conv_d6 3.430 -> 3.394 ms.  (Stamps after it: 339 / 168 / 217 / 272 - phase 1 is its
+// twelve reads, not its DMA; reading the k-half-1 fragments - six of the twelve - behind the barrier, under the first eight MFMAs: 3.460 -> 3.496.)
 #if !defined(C256_WB_IN_P4)
 #define STAGE_WB_P1 stage_w1(SLOT_WB, 0, t + 1, sp ^ 1);
 #define STAGE_WB_P2 stage_w1(SLOT_WB, 1, t + 1, sp ^ 1);
