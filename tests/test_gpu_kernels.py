@@ -100,7 +100,8 @@ def test_conv_kernels_vs_torch(case):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
 
 
-@pytest.mark.parametrize('shape', [(1, 8, 32, 64, 1), (2, 16, 64, 256, 4), (3, 24, 96, 128, 2)])
+# (the last shape: 320 tiles of a 64-channel layer on 256 workgroups - one chunk per tile, so every K-tile stages the NEXT tile's halo)
+@pytest.mark.parametrize('shape', [(1, 8, 32, 64, 1), (2, 16, 64, 256, 4), (3, 24, 96, 128, 2), (80, 16, 64, 64, 1)])
 def test_halo_conv256_vs_torch(shape):
     """3x3 dilation-1 convs whose output is covered by 8x32 tiles take the halo-tile kernel
     (conv_mfma256_halo.hip): single and grouped, 1-4 chunks of 64 channels, several tiles per workgroup."""
