@@ -1,5 +1,6 @@
 // Halo-tile form of the persistent 256x256 implicit-GEMM convolution, for layers whose taps all lie
-// within +-1 pixel (the dilation-1 head conv: 4 groups x 256->256, 3x3).
+// within +-1 pixel (the dilation-1 head conv: 4 groups x 256->256, 3x3; the four sub-pixel phases of the neck's 4x4 / stride-2
+// transposed convs: 2x2 taps each).
 //
 // conv_mfma256.hip stages a 256-pixel x 64-channel operand half-tile pair once per (tap, chunk): every
 // input pixel crosses L2 -> LDS nine times per chunk, and the rows a tile needs for dy = +-1 are fetched
@@ -13,9 +14,10 @@
 //
 // Schedule, tickets, bias-in-LDS, 16-byte swapped stores: as the persistent kernel of conv_mfma256.hip.
 // Differences: the weight ring holds only WA/WB half-tiles (64 KB); the halo of the NEXT chunk (or of the
-// next tile's first chunk) is staged in 2*ntaps-1 equal slices, one DMA instruction per wave in each P2 and
-// P3 (<= 64 lanes active, source address computed on the fly from the slice index), so that every K-tile
-// issues the same 0+2+2+2 DMA instructions (P2 / P3: a halo row + half of WA, P4: WB, of K-tile kt+2) and the counted s_waitcnt stays an immediate (vmcnt(6)).
+// next tile's first chunk) is staged one halo ROW per DMA instruction (34 lanes of every wave, the row a running cursor in SGPRs),
+// two rows per K-tile with nine taps, three with four, so that every K-tile issues the same 0+2+2+2 (0+2+2+3) DMA instructions -
+// P2 / P3: a halo row + one half of WA, P4: WB (+ a row), all of K-tile kt+2 - and the counted s_waitcnt stays an immediate
+// (vmcnt(6) / vmcnt(7); the tap count is a template parameter).
 // When there is no next tile the same instructions re-stage data of the current tile into ring slots
 // that are already free: no dummy slot (the LDS is full) and no run-time counts.  (First version: six
 // 512-lane halo DMAs on taps 0-2 and per-phase counts dispatched through a switch: the scalar code of
