@@ -25,6 +25,24 @@ def test_plan_matches_oracle_fp32(bb):
         np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize('nconv', [1, 3])
+def test_plan_header_depths_match_oracle(nconv):
+    """MODEL.HEADER_NUM_CONV = 1 / 3 (models/nets/header.py:12-13): the recorded plan - one fused dilation-6 conv, n - 1 grouped
+    dilation-1 convs ping-ponging between two tensors, the logit convs reading the last one - is the oracle's function (which the
+    reference-run fixtures e2e_dla34_small_nc{1,3}.npz pin); op names as the bench / profiles expect them."""
+    bb = 'RESNET-18'
+    sd = weights.synth_state_dict(bb, 3, 'trained', header_num_conv=nconv)
+    assert ('detect_header.main_kf_header.%d.weight' % (3 * (nconv - 1))) in sd and ('detect_header.main_kf_header.%d.weight' % (3 * nconv)) not in sd
+    x = weights.synth_images(1, 64, 128, seed=5)
+    P = plan_mod.build_plan(sd, bb, 1, 64, 128, header_num_conv=nconv)
+    names = [o['name'] for o in P.ops if o['name'].startswith('heads.')]
+    assert names == ['heads.conv_d6'] + ['heads.conv_d1' if k == 1 else 'heads.conv_d1_%d' % k for k in range(1, nconv)] + ['heads.out_convs'], names
+    outs, _ = run_plan(P, x)
+    _, logits = rtm3d_ref.model_forward(x, sd, bb)
+    for a, b in zip(outs, logits):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=5e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize('bb', ['DLA-34', 'RESNET-18'])
 def test_realize_level_rewrites_keep_the_function(bb):
     """Round 4: the rewrites RealizedPlan applies when it records a plan - a DLA block's `project` 1x1 as extra K-steps of the block's
