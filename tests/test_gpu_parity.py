@@ -330,6 +330,29 @@ def test_sparse_heads_refuse_other_header_depths(dev):
         m.detect(x)
 
 
+def test_pipeline_with_three_header_convs(dev):
+    """MODEL.HEADER_NUM_CONV = 3 through the whole device pipeline (forward -> decode2d -> decode3d -> records): the pipelined step
+    gives the same records as the step-by-step calls, and the detections are those of the reference-run fixture's weights."""
+    from rtm3d_amd.pipeline import Detect3DPipeline
+    from rtm3d_amd import distributed as rdist
+    g = load_golden('e2e_dla34_small_nc3.npz')
+    B, H, W = [int(v) for v in g['shape']]
+    sd = weights.synth_state_dict('DLA-34', int(g['seed']), str(g['style']), heat_bias=float(g['heat_bias']), heat_gain=float(g['heat_gain']),
+                                  header_num_conv=3)
+    m = make_model('DLA-34', sd, nconv=3)
+    x = weights.synth_images(B, H, W, seed=int(g['img_seed'])).to(dev)
+    K = torch.as_tensor(np.tile(g['K'], (B, 1)), dtype=torch.float64, device=dev)
+    det, boxes, _ = m.detect3d(x, K)
+    n = det.n.cpu().numpy()
+    assert abs(int(n.sum()) - int(g['det_n'].sum())) <= 4          # up to fp16 flips at the score threshold
+    rec_ref = rdist.pack_records(det.n, det.cls, det.score, det.mproj, det.verts, det.bbox, det.topk, boxes).clone()
+    pipe = Detect3DPipeline(m, B, dev, gather=False)
+    k = pipe.submit(x, K)
+    rec = pipe.results(k, copy=True)
+    pipe.drain()
+    assert torch.equal(rec, rec_ref)
+
+
 @pytest.mark.parametrize('fname', E2E)
 def test_sparse_heads_detections_vs_reference_golden(dev, fname):
     """Model.detect (peaks-only regression heads) against the REFERENCE's own detections of the reference-run e2e fixtures: as
