@@ -336,20 +336,20 @@ def parity_check(model, cfg, sd, backbone, x_dev, k, dev, planted=16, draws=2, s
             st['box_linf'] = max(st['box_linf'], float(dv.max()))
     st['boxes'] = _box_stats(st_boxd)
     st['solver_form'] = solver_form                # the form of rtm3d_decode3d_slots the timed step (and this block) ran
-    # the same stage inputs through the solver's PUBLISHED form (L-BFGS-B's subspace step, the form SciPy runs; one lane per
-    # object: the flat cross-check entry): tells an implementation difference of the direct two-loop form from an object on
-    # which any two correct implementations stop an iteration apart
+    # the same stage inputs through the solver's OTHER form (the flat entry rtm3d_decode3d): with the default - the published
+    # subspace step SciPy runs - in the timed step this is the opt-in direct two-loop form, and the other way round
     from rtm3d_amd.model_utils import solve_boxes
-    pub_boxd, pub_nit = [], 0
+    other = 'direct' if solver_form == 'published' else 'published'
+    oth_boxd, oth_nit = [], 0
     for b in range(k):
         if raws_p[b] is None:
             continue
-        xp, fp_, nitp, _ = solve_boxes(dets_p[0][b].numpy(), dets_p[3][b].numpy(), K, dim_ref, [0, -0.5, 20], device=dev, reference_form=True)
+        xp, fp_, nitp, _ = solve_boxes(dets_p[0][b].numpy(), dets_p[3][b].numpy(), K, dim_ref, [0, -0.5, 20], device=dev, form=other)
         both = raws_p[b]['kept'] & (fp_ < 0.1)
-        pub_nit += int((nitp != raws_p[b]['nit'])[both].sum())
+        oth_nit += int((nitp != raws_p[b]['nit'])[both].sum())
         if both.any():
-            pub_boxd.extend(list(angle_diff(box_params(xp[both]), box_params(raws_p[b]['x'][both]))))
-    st['published_form'] = {'boxes': _box_stats(pub_boxd), 'iteration_count_differs': pub_nit}
+            oth_boxd.extend(list(angle_diff(box_params(xp[both]), box_params(raws_p[b]['x'][both]))))
+    st[other + '_form'] = {'boxes': _box_stats(oth_boxd), 'iteration_count_differs': oth_nit}
     out['stage'] = st
     # ---------------------------------------------------------------- end to end (fp16 network on the device)
     def match_e2e(det, boxes, dets_o, raws, only_cells=None):
@@ -840,11 +840,10 @@ def main():
                           'solver_form': args.solver_form or _default_solver_form()},
                'roofline': roof, 'multi_gpu': multi}
         # the plan-level A/B switches this process ran with (environment, read once at import: rtm3d_amd/plan.py); the product: all True
-        # but NECK_LANES (opt-in)
         from rtm3d_amd import plan as _p
         out['config']['plan_switches'] = {'FOLD_PROJECT_C128': _p.FOLD_PROJECT_C128, 'FOLD_NECK_UP': _p.FOLD_NECK_UP, 'USE_CONV64S2': _p.USE_CONV64S2,
-                                          'S2D_ONLY': _p.S2D_ONLY, 'USE_CONV128': _p.USE_CONV128, 'NECK_LANES': _p.NECK_LANES}
-        if not all(v for k_, v in out['config']['plan_switches'].items() if k_ != 'NECK_LANES') or out['config']['plan_switches']['NECK_LANES']:
+                                          'S2D_ONLY': _p.S2D_ONLY, 'USE_CONV128': _p.USE_CONV128}
+        if not all(out['config']['plan_switches'].values()):
             out['DIAGNOSTIC_plan_switches'] = 'a plan-level A/B switch is off: not the product configuration'
         if args.diag_no_decode3d:
             out['INVALID'] = 'diagnostic run without the 3D decode'

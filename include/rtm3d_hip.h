@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTM3D_ABI_VERSION 8
+#define RTM3D_ABI_VERSION 9
 #define RTM3D_MAX_GROUPS 4
 #define RTM3D_MAX_TAPS 80
 
@@ -206,18 +206,10 @@ int rtm3d_ctx_debug_read_words(rtm3d_ctx* ctx, int offset, int n, unsigned int* 
  * up on graphs - Model.forward_logits(out=...) keeps the addresses stable).  Any pointer may be NULL.                      */
 int rtm3d_ctx_graph_stats(rtm3d_ctx* ctx, int* captures, int* hits, int* enabled);
 
-/* REPLAY SCHEDULE (round 5, ABI 8).  By default every op runs on the caller's stream in the order it was recorded.  An op may be
- * put on one of three SIDE LANES (lane 1..3: a stream the context owns) - ops of different lanes may then run at the same time,
- * so that the fill and drain of one persistent launch overlaps another launch (the neck's three independent up-sampling chains,
- * models/nets/keypoint_fpn_fusion.py:60-69, ride beside its top-down chain :35-46).  wait_ops: the EARLIER ops of OTHER lanes
- * this op depends on (read-after-write, write-after-read and write-after-write on any tensor); order within a lane is the
- * stream's.  The caller's stream continues behind every lane at the end of a replay.  Results do not depend on the schedule
- * (every kernel is deterministic).  Graph replays (rtm3d_ctx_set_graph) and rtm3d_forward_timed ignore the lanes: plan order
- * on one stream is a valid order of the same dependency graph.  rtm3d_ctx_set_lanes(ctx, 0) switches the lanes off (A/B).  */
-int rtm3d_op_schedule(rtm3d_ctx* ctx, int op_index, int lane, int n_wait, const int* wait_ops);
-int rtm3d_ctx_set_lanes(rtm3d_ctx* ctx, int enable);
-/* Wall time of STAGES of one eager replay with its lanes: events on the caller's stream in front of the ops mark_ops[0..n_marks)
- * (ascending indices of lane-0 ops; n_marks <= 8) and behind the last op; h_ms[i] = mark i -> mark i + 1 (the last: -> end).   */
+/* Wall time of STAGES of one eager replay: events on the caller's stream in front of the ops mark_ops[0..n_marks) (ascending op
+ * indices; n_marks <= 8) and behind the last op; h_ms[i] = mark i -> mark i + 1 (the last: -> end).  (ABI 9: the side-lane replay
+ * schedule of ABI 8 - rtm3d_op_schedule / rtm3d_ctx_set_lanes - is gone: measured as no gain for the forward and a slower
+ * two-stream pipeline, profiles/r05_neck_lanes.txt.)                                                                        */
 int rtm3d_forward_marks(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
                         int n_marks, const int* mark_ops, float* h_ms);
 
@@ -271,31 +263,31 @@ int rtm3d_decode2d_finish(void* stream, int B, int topk, const int32_t* d_n, con
  * L-BFGS-B (m=10, factr=1e7, pgtol=1e-5, maxls=20, unbounded) started at
  * [0,1,l_ref,h_ref,w_ref,ref_loc].  Replaces optim_decode_bbox3d, utils/model_utils.py:264-312
  * (objective :155-177, gradient :206-234) and scipy.optimize.minimize(method='L-BFGS-B').
- * Iteration driver, More'-Thuente line search, BFGS skip rule and stopping tests follow L-BFGS-B 3.0 step by step; the
- * search direction -B^-1 g of the unbounded case is computed by the two-loop recursion over the stored pairs instead of the
- * published subspace step (formk / subsm) - the same vector in exact arithmetic, a third of the dependent fp64 operations
- * (rtm3d_amd/csrc/lbfgsb.h; rtm3d_decode3d_reference_form below runs the published step for comparison).
+ * Iteration driver, More'-Thuente line search, BFGS skip rule and stopping tests follow L-BFGS-B 3.0 step by step.
+ * `form` selects how the search direction -B^-1 g of the unbounded case is computed (one wavefront per object either way):
+ *   RTM3D_SOLVER_PUBLISHED  L-BFGS-B 3.0's published subspace step (formk / subsm / formt) - the arithmetic SciPy runs behind
+ *                           utils/model_utils.py:295-296, operation for operation.  THE PRODUCT'S DEFAULT since ABI 9 (the
+ *                           Python facade passes it unless told otherwise): on every reference-run fixture all kept boxes
+ *                           are within 1e-4 of SciPy's.  Bit-identical to rtm3d_decode3d_reference_form.
+ *   RTM3D_SOLVER_DIRECT     the two-loop recursion over the stored pairs - the same vector in exact arithmetic, a third of the
+ *                           dependent fp64 operations per iteration (rtm3d_amd/csrc/lbfgsb.h); keep / reject identical, but one
+ *                           kept object in ~1000 stops an iteration apart from SciPy (99.1-100 % within 1e-4 per fixture;
+ *                           DESIGN.md section 4).  Opt-in.  Bit-identical to rtm3d_decode3d_scalar.
  *   d_cls[N] int64, d_verts[N*16] fp32, d_K[N*9] fp64 (row-major 3x3 per object),
  *   d_dim_ref[ncls*3] fp64 (h,w,l), d_ref_loc[3] fp64.
  * Outputs: d_x[N*8] fp64 final iterate, d_fun[N] fp64, d_nit[N] int32, d_status[N] int32
  * (0 converged, 1 max iterations, 2 abnormal line search, 3 non-finite objective at the start point:
  * NaN / Inf key points give x = x0, fun = NaN, nit = 0 like SciPy does).  The caller applies `fun < 0.1`. */
+#define RTM3D_SOLVER_DIRECT 0
+#define RTM3D_SOLVER_PUBLISHED 1
 int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                    const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
-                   double* d_fun, int32_t* d_nit, int32_t* d_status);
+                   double* d_fun, int32_t* d_nit, int32_t* d_status, int form);
 
 /* Same solver over the fixed-size slots written by rtm3d_decode2d, without a host round trip:
  * slot i = (image i / topk, rank i % topk) is solved iff rank < d_n[image]; other slots get
  * status -1 and are otherwise untouched.  d_K_per_image[B*9].  Outputs have B*topk rows.
- * form (ABI 8) selects the search direction of the wave-cooperative solver on this, the product path:
- *   RTM3D_SOLVER_DIRECT     two-loop recursion over the stored pairs (rtm3d_decode3d's arithmetic; the cheaper one);
- *   RTM3D_SOLVER_PUBLISHED  L-BFGS-B 3.0's published subspace step (formk / subsm / formt) - the arithmetic SciPy runs behind
- *                           utils/model_utils.py:295-296; bit-identical to rtm3d_decode3d_reference_form, ~2.4x the cycles per
- *                           iteration and 67 KB of LDS per 8-object workgroup (+0.16 ms per bs=32 step at ~470 objects).
- * On identical inputs both agree with the reference's SciPy results on keep / reject; kept boxes: published form 100 % within
- * 1e-4 on every fixture, direct form 99.1-100 % (one object in ~1000 ends an iteration apart).          */
-#define RTM3D_SOLVER_DIRECT 0
-#define RTM3D_SOLVER_PUBLISHED 1
+ * form: as for rtm3d_decode3d.                                                                                              */
 int rtm3d_decode3d_slots(void* stream, int B, int topk, const int32_t* d_n, const int64_t* d_cls,
                          const float* d_verts, const double* d_K_per_image, const double* d_dim_ref, int ncls,
                          const double* d_ref_loc, double* d_x, double* d_fun, int32_t* d_nit, int32_t* d_status, int form);
@@ -359,10 +351,11 @@ int rtm3d_input_tensor(rtm3d_ctx* ctx, void** d_base, int* B, int* H, int* W, in
 int rtm3d_stream_create_cumask(int device, int n_cus, void** stream);
 int rtm3d_stream_destroy(void* stream);
 
-/* Cross-check entries, identical arguments to rtm3d_decode3d, one lane per object (slow; parity tests only):
- *   rtm3d_decode3d_scalar          the product's arithmetic: results bit-identical to rtm3d_decode3d;
+/* Cross-check entries, the arguments of rtm3d_decode3d without `form`, one lane per object (slow; parity tests only):
+ *   rtm3d_decode3d_scalar          the direct form: results bit-identical to rtm3d_decode3d(form = RTM3D_SOLVER_DIRECT);
  *   rtm3d_decode3d_reference_form  L-BFGS-B 3.0 with its published subspace step (formk / subsm / formt), the form
- *                                  scipy.optimize.minimize(method='L-BFGS-B') runs (utils/model_utils.py:295-296).              */
+ *                                  scipy.optimize.minimize(method='L-BFGS-B') runs (utils/model_utils.py:295-296): bit-identical
+ *                                  to rtm3d_decode3d(form = RTM3D_SOLVER_PUBLISHED).                                            */
 int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                           const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                           double* d_fun, int32_t* d_nit, int32_t* d_status);

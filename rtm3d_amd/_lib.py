@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_C', 'librtm3d_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_GROUPS, MAX_TAPS = 4, 80
 
 c_int, c_void_p, c_float, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
@@ -84,8 +84,6 @@ SIGNATURES = {
     'rtm3d_ctx_debug_read_words': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'rtm3d_ctx_graph_stats': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'rtm3d_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int)]),
-    'rtm3d_op_schedule': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
-    'rtm3d_ctx_set_lanes': (c_int, [c_void_p, c_int]),
     'rtm3d_forward_marks': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     'rtm3d_op_info': (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_char_p)]),
     'rtm3d_probe_set': (c_int, [c_void_p, c_int]),
@@ -94,7 +92,7 @@ SIGNATURES = {
     'rtm3d_decode2d': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rtm3d_decode3d': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_int]),
     'rtm3d_pack_records': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_double, c_void_p]),
     'rtm3d_project_boxes': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -37,9 +37,17 @@ class CheckPointer(object):
         if not f:
             logger.info('No checkpoint found. Initializing model from scratch')
             return {}
-        ckpt = torch.load(f, map_location='cpu')
-        sd = ckpt['model'] if 'model' in ckpt else ckpt
-        if self.mode == 'full' and hasattr(sd, 'state_dict'):
-            sd = sd.float().state_dict()
+        # weights_only=True, stated: tensors and plain containers only, nothing from the file is executed (N ranks of a multi-GPU
+        # start all read it).  The reference's mode='full' files pickle the whole nn.Module (utils/check_point.py:120-122,
+        # torch.save({'model': model})): unpickling one would run code from the file, so it is refused with the way out.
+        try:
+            ckpt = torch.load(f, map_location='cpu', weights_only=True)
+        except Exception as e:
+            raise RuntimeError("CheckPointer.load: %r is not a tensors-only checkpoint (%s: %s).  A mode='full' file of the reference "
+                               "holds a pickled module; re-save it with the reference as {'model': model.state_dict()} "
+                               "(its mode='state-dict', utils/check_point.py:123-124) and load that." % (f, type(e).__name__, e)) from e
+        sd = ckpt['model'] if isinstance(ckpt, dict) and 'model' in ckpt else ckpt
+        if not isinstance(sd, dict) or not all(torch.is_tensor(v) for v in sd.values()):
+            raise RuntimeError("CheckPointer.load: %r does not hold a state dict of tensors under 'model'" % (f,))
         load_state_dict(self.model, sd)
         return ckpt

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 #ifndef D3_WPB_DEFAULT
 #define D3_WPB_DEFAULT 8
 #endif
+#ifndef D3_WPB_PUB
+#define D3_WPB_PUB 8
+#endif
 // FORM 0: the direct form (two-loop search direction, lbfgsb_wave.h) - the default of the product path;
 // FORM 1: the published subspace step (lbfgsb_wave_pub.h: what SciPy runs), selectable on the product path since round 5
 // (rtm3d_decode3d_slots form = 1): 8.4 KB of LDS per object, i.e. 67 KB per workgroup of eight.
@@ -109,18 +112,20 @@ extern void rt_set_error(const char* fmt, ...);
 
 #define D3_LAUNCH(...) hipLaunchKernelGGL((decode3d_wave_kernel<D3_WPB_DEFAULT, 0>), dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
                                           dim3(64 * D3_WPB_DEFAULT), 0, (hipStream_t)stream, __VA_ARGS__)
-#define D3_LAUNCH_PUB(...) hipLaunchKernelGGL((decode3d_wave_kernel<D3_WPB_DEFAULT, 1>), dim3((N + D3_WPB_DEFAULT - 1) / D3_WPB_DEFAULT), \
-                                              dim3(64 * D3_WPB_DEFAULT), 0, (hipStream_t)stream, __VA_ARGS__)
+#define D3_LAUNCH_PUB(...) hipLaunchKernelGGL((decode3d_wave_kernel<D3_WPB_PUB, 1>), dim3((N + D3_WPB_PUB - 1) / D3_WPB_PUB), \
+                                              dim3(64 * D3_WPB_PUB), 0, (hipStream_t)stream, __VA_ARGS__)
 
 extern "C" int rtm3d_decode3d(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                               const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
-                              double* d_fun, int32_t* d_nit, int32_t* d_status) {
+                              double* d_fun, int32_t* d_nit, int32_t* d_status, int form) {
     if (N < 0 || ncls <= 0) { rt_set_error("decode3d: bad sizes"); return 1; }
+    if (form != RTM3D_SOLVER_DIRECT && form != RTM3D_SOLVER_PUBLISHED) { rt_set_error("decode3d: unknown solver form %d (0 = direct two-loop direction, 1 = published subspace step)", form); return 1; }
     if (N == 0) return 0;
     if (!d_cls || !d_verts || !d_K || !d_dim_ref || !d_ref_loc || !d_x || !d_fun || !d_nit || !d_status) {
         rt_set_error("decode3d: null pointer"); return 1;
     }
-    D3_LAUNCH(N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    if (form == RTM3D_SOLVER_PUBLISHED) D3_LAUNCH_PUB(N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
+    else D3_LAUNCH(N, d_cls, d_verts, d_K, d_dim_ref, ncls, d_ref_loc, d_x, d_fun, d_nit, d_status, (const int32_t*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rt_set_error("decode3d launch: %s", hipGetErrorString(e)); return 1; }
     return 0;

@@ -35,12 +35,6 @@ struct Op {
     double flops, bytes;
     ConvKArgs conv; int groups, bn_tile, epi_nchw, out_slot, ksize;
     int ticket_slot = -1;           // conv64_halo: index of this op's ticket counter (ctx->tile_ctr + 8 + slot)
-    // replay schedule (rtm3d_op_schedule): ops of lane 0 run on the caller's stream in plan order; an op of lane 1..3 runs on the
-    // context's side stream of that lane after the events of `waits` (ops of OTHER lanes it depends on; same-lane order is the stream's)
-    int lane = 0;
-    std::vector<int> waits;
-    bool signals = false;           // another lane waits for this op: an event is recorded behind it
-    hipEvent_t ev = nullptr;
     float* stat_out = nullptr;      // softmax partials written by this conv's epilogue (halo kernel), or null
     StemKArgs stem; int stem_cout;
     PoolKArgs pool;
@@ -85,12 +79,6 @@ struct rtm3d_ctx {
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0, graph_hits = 0, graph_captures = 0, graph_refused = 0;
     int test_memset_in_replay = 0;     // rtm3d_ctx_debug_memset_in_replay: a hipMemsetAsync in front of every replay (tests the guard above)
-    // side streams of the replay schedule (lanes 1..3) and the events that join them back into the caller's stream
-    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t lane_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t replay_head = nullptr;
-    int lanes_enabled = 1;
-    unsigned long long lane_replays = 0;
     // stage marks (rtm3d_forward_marks): events on the caller's stream in front of given ops of ONE replay, and one behind the last op
     int n_marks = 0;
     int mark_op[8];
@@ -100,9 +88,7 @@ struct rtm3d_ctx {
 static const int PROBE_RING = 64;
 static const int TICKET_SLOTS = 56;
 static const int SPLIT_CTRS = 256;       // per-tile arrival counters of the split-K convolutions (self-resetting, shared by all ops)
-static const int RT_LANES = 4;
-static const size_t LANE_CTR0 = 8 + TICKET_SLOTS + SPLIT_CTRS;      // per-XCD ticket counters of the persistent conv256 kernels, lanes 1..3
-static const size_t TILE_CTR_WORDS = LANE_CTR0 + 8 * (RT_LANES - 1);   // (concurrent launches must not share the self-resetting counters)
+static const size_t TILE_CTR_WORDS = 8 + TICKET_SLOTS + SPLIT_CTRS;
 static const size_t DEBUG_WORD0 = 1024;           // diagnostic builds (-DC256_STAMPS) dump in-kernel stamps behind the counters
 static const size_t DEBUG_WORDS = 16384;
 
@@ -142,12 +128,6 @@ extern "C" void rtm3d_ctx_destroy(rtm3d_ctx* ctx) {
     for (auto p : ctx->blobs) (void)hipFree(p);
     for (auto p : ctx->extra) (void)hipFree(p);
     for (auto e : ctx->probe_ev) (void)hipEventDestroy(e);
-    for (auto& op : ctx->ops) if (op.ev) (void)hipEventDestroy(op.ev);
-    if (ctx->replay_head) (void)hipEventDestroy(ctx->replay_head);
-    for (int l = 1; l < RT_LANES; ++l) {
-        if (ctx->lane_join[l]) (void)hipEventDestroy(ctx->lane_join[l]);
-        if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
-    }
     for (auto& ge : ctx->graphs) { (void)hipGraphExecDestroy(ge.exec); (void)hipGraphDestroy(ge.graph); }
     if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
     if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
@@ -768,10 +748,9 @@ extern "C" int rtm3d_op_softmax_fuse(rtm3d_ctx* ctx, int z_in, int z_out, int n_
     return 0;
 }
 
-static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, float* const d_out[4], int lane = 0) {
+static int launch_op(rtm3d_ctx* ctx, Op& op, hipStream_t s, const float* d_in, float* const d_out[4]) {
     hipError_t e = hipSuccess;
-    // the conv256 kernels' shared per-XCD ticket counters: one set per lane (launches of different lanes may run at the same time)
-    unsigned int* const ctr256 = ctx->tile_ctr ? ctx->tile_ctr + (lane ? LANE_CTR0 + 8 * (size_t)(lane - 1) : 0) : nullptr;
+    unsigned int* const ctr256 = ctx->tile_ctr;       // the conv256 kernels' shared per-XCD ticket counters
     switch (op.kind) {
         case OP_CONV_MFMA: {
             ConvKArgs a = op.conv;
@@ -831,49 +810,17 @@ static int replay_eager(rtm3d_ctx* ctx, hipStream_t s, const float* d_in, float*
     RT_HIP(zero_counters(ctx, s));
     if (ctx->test_memset_in_replay && ctx->tile_ctr) RT_HIP(hipMemsetAsync(ctx->tile_ctr, 0, sizeof(unsigned int), s));   // (test hook only)
     const int n = (int)ctx->ops.size();
-    // lanes: `probes` is false only while a hipGraph is being captured (one stream there: plan order is a valid order of the DAG)
-    bool lanes = probes && ctx->lanes_enabled;
-    if (lanes) {
-        lanes = false;
-        for (auto& o : ctx->ops) if (o.lane) { lanes = true; break; }
-    }
-    if (lanes) {
-        if (!ctx->replay_head) RT_HIP(hipEventCreateWithFlags(&ctx->replay_head, hipEventDisableTiming));
-        RT_HIP(hipEventRecord(ctx->replay_head, s));
-    }
-    bool used[RT_LANES] = {false, false, false, false};
     for (int i = 0; i < n; ++i) {
         Op& op = ctx->ops[i];
-        const int lane = lanes ? op.lane : 0;
-        hipStream_t st = s;
-        if (lane) {
-            if (!ctx->lane_stream[lane]) {
-                RT_HIP(hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking));
-                RT_HIP(hipEventCreateWithFlags(&ctx->lane_join[lane], hipEventDisableTiming));
-            }
-            st = ctx->lane_stream[lane];
-            // a side lane never runs ahead of the replay it belongs to: its first op also waits for the HEAD of this replay on the
-            // caller's stream (write-after-read against the previous replay's lane-0 ops) - not for the point the caller's stream has
-            // reached by now: the ops come up in plan order, and that would put the lane behind every lane-0 op recorded before it
-            if (!used[lane]) RT_HIP(hipStreamWaitEvent(st, ctx->replay_head, 0));
-            used[lane] = true;
-        }
-        if (lanes)
-            for (int w : op.waits) if (ctx->ops[w].lane != lane) RT_HIP(hipStreamWaitEvent(st, ctx->ops[w].ev, 0));
         for (int m = 0; m < ctx->n_marks; ++m)
-            if (ctx->mark_op[m] == i) RT_HIP(hipEventRecord(ctx->mark_ev[m], s));      // (mark ops are lane-0 join points)
+            if (ctx->mark_op[m] == i) RT_HIP(hipEventRecord(ctx->mark_ev[m], s));
         const bool probe = probes && (i == ctx->probe_op);
         const int slot = ctx->probe_count % PROBE_RING;
-        if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], st));
-        if (launch_op(ctx, op, st, d_in, d_out_logits, lane)) return 1;
-        if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], st)); ctx->probe_count++; }
-        if (lanes && op.signals) RT_HIP(hipEventRecord(op.ev, st));
+        if (probe) RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot], s));
+        if (launch_op(ctx, op, s, d_in, d_out_logits)) return 1;
+        if (probe) { RT_HIP(hipEventRecord(ctx->probe_ev[2 * slot + 1], s)); ctx->probe_count++; }
     }
-    // whatever a side lane still runs belongs to this replay: the caller's stream continues behind it
-    for (int l = 1; l < RT_LANES; ++l)
-        if (used[l]) { RT_HIP(hipEventRecord(ctx->lane_join[l], ctx->lane_stream[l])); RT_HIP(hipStreamWaitEvent(s, ctx->lane_join[l], 0)); }
     if (ctx->n_marks) RT_HIP(hipEventRecord(ctx->mark_ev[ctx->n_marks], s));
-    if (lanes) ctx->lane_replays++;
     return 0;
 }
 
@@ -1002,33 +949,6 @@ extern "C" int rtm3d_ctx_debug_memset_in_replay(rtm3d_ctx* ctx, int enable) {
     return 0;
 }
 
-extern "C" int rtm3d_op_schedule(rtm3d_ctx* ctx, int op_index, int lane, int n_wait, const int* wait_ops) {
-    if (!ctx || op_index < 0 || op_index >= (int)ctx->ops.size() || lane < 0 || lane >= RT_LANES || n_wait < 0 || (n_wait && !wait_ops))
-        RT_FAIL("op_schedule: bad arguments (op %d, lane %d, %d waits)", op_index, lane, n_wait);
-    Op& op = ctx->ops[op_index];
-    for (int i = 0; i < n_wait; ++i) {
-        const int w = wait_ops[i];
-        if (w < 0 || w >= op_index) RT_FAIL("op_schedule: op %d may only wait for earlier ops (got %d)", op_index, w);
-    }
-    // an op on a side lane draws from that lane's conv256 ticket counters; the other ticketed kernels have a counter per op
-    op.lane = lane;
-    op.waits.assign(wait_ops, wait_ops + n_wait);
-    for (int w : op.waits) {
-        Op& p = ctx->ops[w];
-        p.signals = true;
-        if (!p.ev) RT_HIP(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
-    }
-    if (lane && ensure_tile_ctr(ctx)) return 1;
-    if (lane && op.kind == OP_CONV_MFMA && op.conv.ksplit > 1) RT_FAIL("op_schedule: split-K launches share their arrival counters and stay on lane 0");
-    return 0;
-}
-
-extern "C" int rtm3d_ctx_set_lanes(rtm3d_ctx* ctx, int enable) {
-    if (!ctx) RT_FAIL("ctx_set_lanes: null context");
-    ctx->lanes_enabled = enable ? 1 : 0;
-    return 0;
-}
-
 extern "C" int rtm3d_ctx_debug_read_words(rtm3d_ctx* ctx, int offset, int n, unsigned int* h_out) {
     if (!ctx || !h_out || offset < 0 || n < 1 || (size_t)offset + (size_t)n > DEBUG_WORDS) RT_FAIL("ctx_debug_read_words: bad arguments");
     if (ensure_tile_ctr(ctx)) return 1;
@@ -1095,16 +1015,15 @@ extern "C" int rtm3d_forward_timed(rtm3d_ctx* ctx, void* stream, const float* d_
     return rc ? 1 : 0;
 }
 
-// Wall time of STAGES of one real replay (eager, with its lanes): an event on the caller's stream in front of each op of
-// mark_ops[] (ascending; each must be a lane-0 op whose cross-lane producers it waits for - a join point, e.g. the first op of the
-// backbone, of the neck and of the heads) and one behind the last op; h_ms[i] = time from mark i to mark i + 1 (the last: to the end).
-// The per-op pass (rtm3d_forward_timed) runs the ops one after the other on one stream and cannot see what the lanes overlap.
+// Wall time of STAGES of one real eager replay: an event on the caller's stream in front of each op of mark_ops[] (ascending, e.g.
+// the first op of the backbone, of the neck and of the heads) and one behind the last op; h_ms[i] = time from mark i to mark i + 1
+// (the last: to the end).  Unlike the per-op pass (rtm3d_forward_timed) nothing is synchronised between the ops.
 extern "C" int rtm3d_forward_marks(rtm3d_ctx* ctx, void* stream, const float* d_in, float* const d_out_logits[4],
                                    int n_marks, const int* mark_ops, float* h_ms) {
     if (!ctx || !d_out_logits || !d_out_logits[0] || !mark_ops || !h_ms || n_marks < 1 || n_marks > 8) RT_FAIL("forward_marks: bad arguments");
     for (int i = 0; i < n_marks; ++i)
-        if (mark_ops[i] < 0 || mark_ops[i] >= (int)ctx->ops.size() || (i && mark_ops[i] <= mark_ops[i - 1]) || ctx->ops[mark_ops[i]].lane != 0)
-            RT_FAIL("forward_marks: mark %d (op %d) must be an ascending index of a lane-0 op", i, mark_ops[i]);
+        if (mark_ops[i] < 0 || mark_ops[i] >= (int)ctx->ops.size() || (i && mark_ops[i] <= mark_ops[i - 1]))
+            RT_FAIL("forward_marks: mark %d (op %d) must be an ascending op index", i, mark_ops[i]);
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     hipError_t e = hipSuccess;

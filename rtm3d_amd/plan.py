@@ -28,12 +28,6 @@ FUSE_LEVEL_ENTRY = True   # DLA level2 entry: 2x2 max-pool + 1x1 project + 3x3 s
 FUSE_LEVEL_TAIL = True    # DLA level2 tail: tree2.conv2 + residual, the root 1x1 and the next level's 2x2 max-pool in one launch (conv64_root.hip)
 FOLD_PROJECT = True       # DLA levels 3-5: a block's `project` 1x1 (on the pooled input) as extra K-steps of the block's second conv
 FOLD_PROJECT_C128 = os.environ.get('RTM3D_FOLD_C128', '1') != '0'  # ... also where that conv would otherwise take conv128_halo (level3), which has no one-tap chunk: generic kernel
-# The neck's three up-sampling chains on side lanes of the replay (RealizedPlan._schedule, rtm3d_op_schedule).  OFF by default:
-# measured at bs=32 (profiles/r05_neck_lanes.txt) the lanes do overlap (rocprofv3 trace), the neck stage takes 2.82 instead of
-# 2.96 ms of wall time - and the head convs behind it take 0.14 ms MORE (7.94 vs 7.80): the forward loop runs 12.90 ms either way
-# (the chip is power-limited over the whole forward: cycles recovered by packing launches closer come back as clock), and the
-# two-stream detection pipeline is 2.4 ms per step SLOWER with the lanes on.  Kept as an opt-in (RTM3D_NECK_LANES=1, tested).
-NECK_LANES = os.environ.get('RTM3D_NECK_LANES', '0') != '0'
 FOLD_NECK_UP = os.environ.get('RTM3D_FOLD_NECK_UP', '1') != '0'   # neck: proj+head 1x1 composed INTO the transposed conv in front of it (RealizedPlan._neck_up_folds)
 FUSE_STEM = True        # DLA stem: base_layer + level0 in one launch (conv_stem_fused.hip); False = two launches (A/B, tests)
 BN_EPS = 1e-4   # utils/torch_utils.py:79-81: initialize_weights sets eps=1e-4 on every BatchNorm2d
@@ -650,35 +644,6 @@ def pack_headout_weights(ws, biases):
     return np.ascontiguousarray(out).astype(np.float16).reshape(-1), bias.reshape(-1)
 
 
-LANE_PREFIXES = ((1, 'fusion_up5'), (2, 'fusion_up4'), (3, 'fusion_up3'))
-
-
-def compute_schedule(op_names, op_rw):
-    """(lane per recorded op, cross-lane wait list per recorded op) - pure host logic, see RealizedPlan._schedule.
-    op_rw[i] = (set of tensors op i reads, set it writes).  Lanes by name (LANE_PREFIXES); an op waits for the LATEST earlier op
-    of every OTHER lane that conflicts with it on some tensor (read-after-write, write-after-read, write-after-write): earlier
-    conflicting ops of that lane are ordered before it by their own stream."""
-    n = len(op_names)
-    lanes = [0] * n
-    for i, name in enumerate(op_names):
-        for lane, pre in LANE_PREFIXES:
-            if name.startswith(pre):
-                lanes[i] = lane
-    waits = [[] for _ in range(n)]
-    if not any(lanes):
-        return lanes, waits
-    for i, (R, W) in enumerate(op_rw):
-        latest = {}
-        for j in range(i):
-            if lanes[j] == lanes[i]:
-                continue
-            Rj, Wj = op_rw[j]
-            if (Wj & (R | W)) or (Rj & W):
-                latest[lanes[j]] = j
-        waits[i] = sorted(latest.values())
-    return lanes, waits
-
-
 class RealizedPlan(object):
     """A Plan recorded into a librtm3d_hip context."""
     def __init__(self, plan, device_index):
@@ -701,7 +666,6 @@ class RealizedPlan(object):
             _lib.check(lib.rtm3d_tensor_create(ctx, plan.B, t['H'], t['W'], t['C'] + widen.get(i, 0), t['pad'], ctypes.byref(tid)), 'tensor_create')
             self.tids.append(tid.value)
         self.op_names = []                      # one entry per RECORDED runtime op (a fused pair records one)
-        self.op_rw = []                         # per recorded op: (set of plan tensors read, set of plan tensors written)
         self.weight_ranges = []                 # per recorded conv: largest |weight| / |bias| as realized (after the level rewrites)
         fused = self._stem_fusion_pairs() if FUSE_STEM else {}
         entry = self._level_entry_triples() if FUSE_LEVEL_ENTRY else {}
@@ -734,14 +698,12 @@ class RealizedPlan(object):
                 chain = [plan.ops[j] for j in fused[k]]
                 self._op_stem_fused(op, *chain)
                 self.op_names.append('+'.join([op['name']] + [c['name'].split('.')[-1] for c in chain]))
-                self.op_rw.append(self._rw(op, *chain))
                 skip.update(fused[k])
                 continue
             if k in entry:
                 proj, conv = plan.ops[entry[k][0]], plan.ops[entry[k][1]]
                 self._op_conv32s2_fused(op, proj, conv)
                 self.op_names.append(op['name'] + '+project+' + conv['name'].split('.', 2)[-1])
-                self.op_rw.append(self._rw(op, proj, conv))
                 skip.update(entry[k])
                 continue
             if k in tail:
@@ -751,7 +713,6 @@ class RealizedPlan(object):
                 self._op_conv64_root(op, root, pool, s2d=(f['hs'], plan.tensors[f['hs'].tid]['C']) if f else None,
                                      skip_out=bool(f and f.get('s2d_only')))
                 self.op_names.append(op['name'] + '+root' + ('+' + pool['name'].split('.', 1)[-1] if pool else '') + ('+s2d' if f else ''))
-                self.op_rw.append(self._rw(op, root, *([pool] if pool else []), extra_w=[f['hs'].tid] if f else []))
                 skip.update(tail[k])
                 continue
             if k in folded_by:
@@ -761,60 +722,12 @@ class RealizedPlan(object):
                 if kind == 'pool':
                     _lib.check(self.lib.rtm3d_op_maxpool_s2d(self.ctx, self.tids[hs_.tid], base_, self.tids[op['out'].tid], op['out'].coff, cf_), 'op_maxpool_s2d ' + op['name'])
                     self.op_names.append(op['name'])
-                    self.op_rw.append(({hs_.tid}, {op['out'].tid}))
                     continue
                 op = self._s2d_input_conv(op, hs_, base_, cf_)
             if k in neck_by:
                 op = self._neck_fold_conv(neck_by[k])
             getattr(self, '_op_' + op['op'])(op)
             self.op_names.append(op['name'])
-            s2 = getattr(self, '_s2d_for', {}).get(k)
-            self.op_rw.append(self._rw(op, extra_w=[s2[0].tid] if s2 is not None else []))
-        self._schedule()
-
-    @staticmethod
-    def _rw(*ops, extra_w=()):
-        """(plan tensors read, plan tensors written) by the recorded op that covers the plan ops `ops` (tensor granularity)."""
-        R, W = set(), set(extra_w)
-        for o in ops:
-            kind = o['op']
-            if kind == 'conv':
-                R.update(i.tid for i in o['inp']); R.update(r.tid for r in o['res'] if r is not None)
-                W.update(t.tid for t in o['out'] if t is not None)
-            elif kind == 'maxpool':
-                R.add(o['inp'].tid); W.add(o['out'].tid)
-            elif kind == 'softmax':
-                R.add(o['z_in'].tid); R.update(u.tid for u in o['us']); W.add(o['z_out'].tid)
-            elif kind == 'headout':
-                R.add(o['inp'].tid)
-            elif kind == 'input4':
-                W.add(o['out'].tid)
-            elif kind == 'patch_mask':
-                R.add(o['t'].tid); W.add(o['t'].tid)
-            else:
-                raise AssertionError('plan: no read / write rule for op kind %r' % kind)
-        return R, W
-
-    def _schedule(self):
-        """Replay schedule (rtm3d_op_schedule): the neck's three up-sampling chains fusion_up5.* / fusion_up4.* / fusion_up3.*
-        (models/nets/keypoint_fpn_fusion.py:60-69: each reads ONE map of the top-down pass and is independent of the other two and
-        of the rest of that pass, :35-46) go to side lanes 1 / 2 / 3; everything else stays on the caller's stream.  The launches of
-        the four chains then overlap: the half-empty last round of a 96 x 320 transposed conv (1920 work items on 256 CUs = 7.5
-        rounds) and the small 24 x 80 / 48 x 160 launches that fill a fraction of the chip run beside another chain's work items.
-        Dependencies across lanes are derived from the recorded ops' tensor reads / writes (RAW, WAR, WAW), latest conflicting op
-        per other lane."""
-        none = ([0] * len(self.op_names), [[] for _ in self.op_names])
-        self.lanes, self.waits = compute_schedule(self.op_names, self.op_rw) if NECK_LANES else none
-        # small launches (the '_deep' ring kernel and its split-K form share their arrival counters between ops) stay in plan order on
-        # one stream: the lanes are for batches whose neck launches are persistent tile loops
-        if any(self.lanes):
-            kn = self.kernel_names()
-            if any(l and '_deep' in kn[i] for i, l in enumerate(self.lanes)):
-                self.lanes, self.waits = none
-        for i in range(len(self.op_names)):
-            if self.lanes[i] or self.waits[i]:
-                w = (ctypes.c_int * max(1, len(self.waits[i])))(*self.waits[i])
-                _lib.check(self.lib.rtm3d_op_schedule(self.ctx, i, self.lanes[i], len(self.waits[i]), w), 'op_schedule')
 
     def _plan_s2d_only(self, nfold, tail):
         """Which feature maps exist ONLY as their space-to-depth copy, and how their remaining readers take it (sets self._in_s2d_for,
@@ -1400,16 +1313,13 @@ class RealizedPlan(object):
         return info
 
     def forward_marks(self, stream, d_in, d_out4, mark_ops):
-        """Wall ms of the stages that start at the recorded ops `mark_ops` (ascending, lane-0 ops) in ONE real replay with its
-        lanes (rtm3d_forward_marks): [mark i -> mark i + 1 ..., last mark -> end]."""
+        """Wall ms of the stages that start at the recorded ops `mark_ops` (ascending) in ONE real eager replay
+        (rtm3d_forward_marks): [mark i -> mark i + 1 ..., last mark -> end]."""
         outs = (ctypes.c_void_p * 4)(*d_out4)
         m = (ctypes.c_int * len(mark_ops))(*mark_ops)
         ms = (ctypes.c_float * len(mark_ops))()
         _lib.check(self.lib.rtm3d_forward_marks(self.ctx, ctypes.c_void_p(stream), ctypes.c_void_p(d_in), outs, len(mark_ops), m, ms), 'forward_marks')
         return [float(v) for v in ms]
-
-    def set_lanes(self, enable):
-        _lib.check(self.lib.rtm3d_ctx_set_lanes(self.ctx, 1 if enable else 0), 'ctx_set_lanes')
 
     def kernel_names(self):
         """Kernel name of every recorded runtime op (rtm3d_op_info), in launch order."""

@@ -206,6 +206,11 @@ def test_state_dict_surface_and_checkpoint(tmp_path):
     CheckPointer(m, mode='state-dict').load(path, use_latest=False)
     assert torch.equal(m.state_dict()['backbone.layer1.0.conv1.weight'], new['backbone.layer1.0.conv1.weight'])
     assert not torch.equal(m.state_dict()['detect_header.main_kf_header.0.weight'], new['detect_header.main_kf_header.0.weight'])
+    # a mode='full' file of the reference pickles the module object (utils/check_point.py:123): refused, nothing is unpickled
+    full = str(tmp_path / 'model_full.pt')
+    torch.save({'model': torch.nn.Linear(2, 2)}, full)
+    with pytest.raises(RuntimeError, match='tensors-only'):
+        CheckPointer(m, mode='full').load(full, use_latest=False)
     with pytest.raises(RuntimeError):
         m.load_state_dict({'backbone.conv1.weight': torch.zeros(1)})
     bad = dict(new); bad['backbone.conv1.weight'] = torch.zeros(64, 3, 3, 3)

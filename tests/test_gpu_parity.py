@@ -128,23 +128,30 @@ def test_decode3d_golden(dev):
     assert e.get_field('dimension').shape == (0, 3) and e.get_field('K').shape == (0, 9) and e.get_field('class') == []
 
 
-def test_decode3d_wave_kernel_equals_scalar_kernel(dev):
-    """The wave-cooperative solver performs the same fp64 operations in the same order as the
-    one-lane-per-object form of lbfgsb.h: results are bit-identical."""
+@pytest.mark.parametrize('form', ['published', 'direct'])
+def test_decode3d_wave_kernel_equals_scalar_kernel(dev, form):
+    """The wave-cooperative solvers perform the same fp64 operations in the same order as the one-lane-per-object forms of
+    lbfgsb.h (published: lb_minimize(direct = 0) = rtm3d_decode3d_reference_form; direct: rtm3d_decode3d_scalar): bit-identical."""
     g = load_golden('decode3d_cases.npz')
-    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
-    b = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], scalar_kernel=True)
+    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], form=form)
+    b = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], scalar_kernel=form == 'direct',
+                                          reference_form=form == 'published')
     for u, v in zip(a, b):
         np.testing.assert_array_equal(u, v)
+    if form == 'published':          # ... and it is what the facade runs when nothing is said
+        assert rtm3d_amd.model_utils.DEFAULT_SOLVER_FORM == 'published'
+        c = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
+        for u, v in zip(a, c):
+            np.testing.assert_array_equal(u, v)
 
 
-def test_decode3d_product_form_vs_published_form(dev):
-    """The product computes the search direction by the two-loop recursion; rtm3d_decode3d_reference_form runs L-BFGS-B's
-    published subspace step (formk / subsm / formt, the form SciPy runs) on the same objects: identical keep / reject
-    decisions, kept boxes within 1e-6 (bar 1e-4); objects the reference rejects are not compared in x (their path is chaotic
-    in either form) but end at the same objective value."""
+def test_decode3d_direct_form_vs_published_form(dev):
+    """The opt-in direct form computes the search direction by the two-loop recursion; the published subspace step (formk / subsm /
+    formt, the form SciPy runs and the product's default) on the same objects: identical keep / reject decisions, kept boxes
+    within 1e-6 (bar 1e-4); objects the reference rejects are not compared in x (their path is chaotic in either form) but end
+    at the same objective value."""
     g = load_golden('decode3d_cases.npz')
-    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'])
+    a = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], form='direct')
     b = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], reference_form=True)
     kept = b[1] < 0.1
     np.testing.assert_array_equal(a[1] < 0.1, kept)
@@ -178,25 +185,26 @@ def _solve_through_slots(g, dev, form, topk=96):
 
 
 # the two forms of the search direction (rtm3d_amd/csrc/lbfgsb.h) and the kernels that run them
-DIRECT_FORM = ('wave', 'scalar', 'slots_direct')                    # two-loop recursion: rtm3d_decode3d, its scalar twin, the slot entry's default
-PUBLISHED_FORM = ('reference_form', 'slots_published')              # formk / subsm (what SciPy runs): the scalar cross-check, the slot entry with form = 1
+PUBLISHED_FORM = ('wave', 'reference_form', 'slots_published')      # formk / subsm (what SciPy runs), THE DEFAULT: rtm3d_decode3d as the facade calls it, the scalar cross-check, the slot entry
+DIRECT_FORM = ('wave_direct', 'scalar', 'slots_direct')             # two-loop recursion (opt-in): rtm3d_decode3d(form = direct), its scalar twin, the slot entry with form = 0
 
 
 @pytest.mark.parametrize('kernel', DIRECT_FORM + PUBLISHED_FORM)
 def test_decode3d_large_fixture(dev, kernel):
-    """the TAIL of the device solvers, pinned.  1536 objects the reference solved (SciPy through
-    its own aimFun / jac; tests/golden/decode3d_large.npz, 876 kept, six noise levels).  Keep / reject identical for every kernel.
-    PUBLISHED form (the arithmetic utils/model_utils.py:295-296 runs through SciPy; on the product path via
-    rtm3d_decode3d_slots(form = 1)): EVERY kept box within north_star's 1e-4 (measured 1.3e-5).  DIRECT form (the product's default,
-    two-loop search direction): >= 99.5 % of the kept boxes within 1e-4, p99 <= 1e-5 - an object in ~1000 ends an iteration
-    apart from SciPy (measured: all 876 within 2.7e-5 on this fixture, 110 of 111 on the bench's planted boxes)."""
+    """The TAIL of the device solvers, pinned.  1536 objects the reference solved (SciPy through its own aimFun / jac;
+    tests/golden/decode3d_large.npz, 876 kept, six noise levels).  Keep / reject identical for every kernel.
+    PUBLISHED form (the arithmetic utils/model_utils.py:295-296 runs through SciPy; the product's default since round 6): EVERY
+    kept box within north_star's 1e-4 (measured 1.3e-5).  DIRECT form (opt-in, two-loop search direction): >= 99.5 % of the kept
+    boxes within 1e-4, p99 <= 1e-5 - an object in ~1000 ends an iteration apart from SciPy (measured: all 876 within 2.7e-5 on
+    this fixture, 110 of 111 on the bench's planted boxes)."""
     from tests.util import solver_tail_stats
     g = load_golden('decode3d_large.npz')
     if kernel.startswith('slots_'):
         x, fun, nit = _solve_through_slots(g, dev, kernel[len('slots_'):])
     else:
         x, fun, nit, _ = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'],
-                                                           scalar_kernel=kernel == 'scalar', reference_form=kernel == 'reference_form')
+                                                           scalar_kernel=kernel == 'scalar', reference_form=kernel == 'reference_form',
+                                                           form='direct' if kernel == 'wave_direct' else None)
     s = solver_tail_stats(x, fun, g)
     record_measurement('decode3d_large_fixture', kernel, s)
     assert s['n'] >= 1500 and s['keep_mismatch'] == 0 and s['kept'] >= 800, s
@@ -204,11 +212,13 @@ def test_decode3d_large_fixture(dev, kernel):
         assert s['within_1e-4'] == 1.0 and s['p99'] <= 1e-5, s
     else:
         assert s['within_1e-4'] >= 0.995 and s['p99'] <= 1e-5, s
-    if kernel == 'wave':
+    if kernel == 'wave':             # the drop-in entry (utils/model_utils.py:264-312) runs the default form: every box within 1e-4
         out = rtm3d_amd.model_utils.optim_decode_bbox3d(g['clses'], g['uv'], g['K'], g['dim_ref'].tolist(), g['ref_loc'].tolist())
         assert out.get_field('class') == g['out_class'].tolist()
-        d = np.abs(np.asarray(out.get_field('dimension')) - g['out_dimension']).max(1)
-        assert (d <= 1e-4).mean() >= 0.995
+        for f in ('dimension', 'location'):
+            assert np.abs(np.asarray(out.get_field(f)) - g['out_' + f]).max() <= 1e-4, f
+        dr = np.abs(np.asarray(out.get_field('Ry')) - g['out_Ry'])
+        assert np.minimum(dr, 2 * np.pi - dr).max() <= 1e-4
     if kernel.startswith('slots_'):
         # the slot entry runs the same arithmetic as the flat cross-check entry of its form: bit for bit
         ref = rtm3d_amd.model_utils.solve_boxes(g['clses'], g['uv'], g['K'], g['dim_ref'], g['ref_loc'], scalar_kernel=kernel == 'slots_direct',
@@ -1071,6 +1081,27 @@ def test_bench_spawn_path_nccl_world1(dev):
     assert out['multi_gpu']['allgather_us_last_step'] > 0 and out['value'] > 0
 
 
+def test_bench_line_parity_of_the_default_solver(dev):
+    """The default `python bench.py` line (DLA-34 bs=32 384x1280; few steps, no CPU baseline here) runs the PUBLISHED solver form in
+    its timed step and its stage parity - the device decode kernels on the oracle's logits with 16 cuboids planted per image -
+    meets north_star on EVERY box the reference keeps: identical indices and keep decisions, box L-inf <= 1e-4."""
+    import subprocess, sys, os, json
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-sparse-probe'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    st = out['parity']['stage']
+    assert out['config']['solver_form'] == 'published' and st['solver_form'] == 'published'
+    assert st['index_mismatches'] == 0 and st['keep_decision_mismatches'] == 0 and st['kept_ref'] >= 100, st
+    assert st['box_linf'] <= 1e-4 and st['boxes']['box_linf']['frac_le_0.0001'] == 1.0, st
+
+
 def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
     """`bench.py --gpus 2 --rehearse-one-gpu`: the launcher starts TWO rank processes that both run the whole hot path on GPU 0 on
     their own shards of the global batch (images rank * B ...) and exchange their records per step from the pipeline's side
@@ -1099,47 +1130,20 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(dev):
     assert out['roofline'] and out['roofline']['launch_ms'] > 0 and out['roofline']['per_stage']['heads']['ms'] > 0
 
 
-def test_replay_lanes_schedule_and_bit_identity(dev):
-    """Round 5: the neck's three up-sampling chains run on side lanes of the replay (rtm3d_op_schedule).  The recorded schedule of
-    the real DLA-34 plan is the dependency structure of keypoint_fpn_fusion.py:35-69; logits with the lanes on are bit-identical to
-    the lanes off (same kernels, same tickets per lane) over repeated and interleaved replays; the stage marks of the lane replay
-    (rtm3d_forward_marks) are positive and the neck's wall time does not exceed the sum of its ops' own times by more than noise."""
-    from rtm3d_amd import plan as plan_mod
+def test_forward_marks_stage_wall_times(dev):
+    """The stage marks of one real eager replay (rtm3d_forward_marks: what bench.py reports as per_stage[*].wall_ms): positive,
+    the neck's wall time within noise of the sum of its ops' own times, logits identical to an ordinary forward; bad mark lists
+    are refused."""
     bb = 'DLA-34'
     sd = weights.synth_state_dict(bb, 1, 'trained', heat_bias=-3.0)
     m = make_model(bb, sd)
     m.use_graph = False
-    B, H, W = 32, 384, 1280                       # (the benchmark shape: a plan with small-launch '_deep' kernels in the neck keeps its lanes off)
+    B, H, W = 32, 384, 1280
     x = weights.synth_images(B, H, W, seed=77).to(dev)
-    was = plan_mod.NECK_LANES
-    plan_mod.NECK_LANES = True                    # (opt-in: off by default, see plan.py)
-    try:
-        plan = m._plan_for(B, H, W, dev)
-    finally:
-        plan_mod.NECK_LANES = was
+    plan = m._plan_for(B, H, W, dev)
     names = plan.op_names
-    idx = {n: i for i, n in enumerate(names)}
-    lane_of = dict(zip(names, plan.lanes))
-    assert {lane_of[n] for n in names if n.startswith('fusion_up5')} == {1}
-    assert {lane_of[n] for n in names if n.startswith('fusion_up4')} == {2}
-    assert {lane_of[n] for n in names if n.startswith('fusion_up3')} == {3}
-    assert all(lane_of[n] == 0 for n in names if not n.startswith('fusion_up'))
-    w = {n: [names[j] for j in plan.waits[i]] for n, i in idx.items()}
-    assert w['fusion_up5.0'] == ['kfpn_head5']
-    assert len(w['fusion_up4.0']) == 1 and w['fusion_up4.0'][0].startswith('kfpn_up5')
-    assert len(w['fusion_up3.0']) == 1 and w['fusion_up3.0'][0].startswith('kfpn_up4')
-    assert sorted(w['kfpn_softmax_fuse']) == ['fusion_up3.0', 'fusion_up4.1', 'fusion_up5.2']
-    assert all(not w[n] for n in names if n.startswith(('backbone', 'heads')))
-    ref = None
-    for rep in range(6):
-        plan.set_lanes(rep % 2 == 0)
-        lg = [t.clone() for t in m.forward_logits(x)]
-        torch.cuda.synchronize()
-        if ref is None:
-            ref = lg
-        for a, b in zip(lg, ref):
-            assert torch.equal(a, b), rep
-    plan.set_lanes(True)
+    ref = [t.clone() for t in m.forward_logits(x)]
+    torch.cuda.synchronize()
     outs = [torch.empty(B, c, H // 4, W // 4, dtype=torch.float32, device=dev) for c in m._head_channels]
     st = torch.cuda.current_stream(dev).cuda_stream
     ptrs = [o.data_ptr() for o in outs]
@@ -1152,11 +1156,10 @@ def test_replay_lanes_schedule_and_bit_identity(dev):
     for a, b in zip(outs, ref):
         assert torch.equal(a, b)
     lib = _lib.load()
-    bad = (ctypes.c_int * 1)(len(names))
-    assert lib.rtm3d_op_schedule(plan.ctx, 3, 1, 1, bad) != 0 and b'earlier' in lib.rtm3d_last_error()
-    assert lib.rtm3d_op_schedule(plan.ctx, 3, 7, 0, None) != 0
+    assert lib.rtm3d_forward_marks(plan.ctx, ctypes.c_void_p(st), ctypes.c_void_p(x.data_ptr()), (ctypes.c_void_p * 4)(*ptrs), 2,
+                                   (ctypes.c_int * 2)(5, 5), (ctypes.c_float * 2)()) != 0      # not ascending
     assert lib.rtm3d_forward_marks(plan.ctx, ctypes.c_void_p(st), ctypes.c_void_p(x.data_ptr()), (ctypes.c_void_p * 4)(*ptrs), 1,
-                                   (ctypes.c_int * 1)(idx['fusion_up5.0']), (ctypes.c_float * 1)()) != 0      # not a lane-0 op
+                                   (ctypes.c_int * 1)(len(names)), (ctypes.c_float * 1)()) != 0
 
 
 def test_graph_replay_is_bit_identical_and_plan_cache_is_bounded(dev):

@@ -265,28 +265,3 @@ def test_peak_plan_equals_dense_heads_at_the_peaks():
     for s, (b, y, xx) in enumerate(peaks):
         np.testing.assert_allclose(pouts[0][s, :, 0, 0].numpy(), outs[1][b, :, y, xx].numpy(), rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(pouts[1][s, :, 0, 0].numpy(), outs[2][b, :, y, xx].numpy(), rtol=2e-4, atol=2e-4)
-
-
-def test_replay_schedule_dependencies():
-    """Round 5: the replay schedule (plan.compute_schedule -> rtm3d_op_schedule).  The neck's three up-sampling chains
-    (models/nets/keypoint_fpn_fusion.py:60-69) go to side lanes; an op waits for the LATEST conflicting op of every other lane
-    (read-after-write, write-after-read, write-after-write on a tensor); ops without a lane prefix stay on lane 0."""
-    from rtm3d_amd.plan import compute_schedule
-    names = ['backbone.l5', 'kfpn_head5', 'kfpn_up5+p5+h4', 'fusion_up5.0', 'kfpn_up4+p4+h3', 'fusion_up5.1', 'fusion_up4.0', 'kfpn_up3+p3+h2',
-             'fusion_up5.2', 'fusion_up4.1', 'fusion_up3.0', 'kfpn_softmax_fuse', 'heads.conv_d6']
-    # tensors: f5 0, h5 1, h4 2, h3 3, z0 4, a5 5, b5 6, u5 7, a4 8, u4 9, u3 10, z 11
-    rw = [(set(), {0}), ({0}, {1}), ({1}, {2}), ({1}, {5}), ({2}, {3}), ({5}, {6}), ({2}, {8}), ({3}, {4}), ({6}, {7}), ({8}, {9}), ({3}, {10}),
-          ({4, 7, 9, 10}, {11}), ({11}, set())]
-    lanes, waits = compute_schedule(names, rw)
-    assert lanes == [0, 0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 0]
-    assert waits[3] == [1] and waits[6] == [2] and waits[10] == [4]          # each chain starts behind the map it reads
-    assert waits[5] == [] and waits[8] == [] and waits[9] == []               # inside a chain: the lane's own stream order
-    assert waits[11] == [8, 9, 10] and waits[12] == []                        # the fusion joins the three chains; heads follow on lane 0
-    # write-after-read: a lane-0 op that overwrites what a side-lane op still reads must wait for it
-    names2 = ['a', 'fusion_up5.0', 'b']
-    rw2 = [(set(), {0}), ({0}, {1}), (set(), {0})]
-    lanes2, waits2 = compute_schedule(names2, rw2)
-    assert lanes2 == [0, 1, 0] and waits2 == [[], [0], [1]]
-    # write-after-write across lanes, and no lane prefixes at all -> nothing scheduled
-    assert compute_schedule(['fusion_up4.0', 'fusion_up3.0'], [(set(), {0}), (set(), {0})])[1] == [[], [0]]
-    assert compute_schedule(['x', 'y'], [(set(), {0}), ({0}, {1})]) == ([0, 0], [[], []])
