@@ -209,6 +209,7 @@ hipError_t launch_conv_mfma(const ConvKArgs& a, int bn_tile, int groups, int epi
 hipError_t launch_conv_mfma_deep(const ConvKArgs& a, int bn_tile, int groups, unsigned int* tile_ctr, hipStream_t s);
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s);
 bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups);
+bool conv_mfma256_uses_lattice(const ConvKArgs& a, int groups);
 bool conv64_halo_supported(const ConvKArgs& a, int groups);
 hipError_t launch_conv64_halo(const ConvKArgs& a, int cu_count, unsigned int* ticket_ctr, hipStream_t s);
 hipError_t launch_conv64_root(const ConvKArgs& a, const RootKArgs& r, int cu_count, unsigned int* ticket_ctr, hipStream_t s);

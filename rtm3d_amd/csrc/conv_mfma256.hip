@@ -699,6 +699,9 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht);
 hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, float* stat_out, hipStream_t s);
+// conv_mfma256_lattice.hip: the halo form for dilated 3x3 layers (tiles on the row sub-lattice of the dilation)
+int conv_mfma256_lattice_dilation(const ConvKArgs& a, int groups);
+hipError_t launch_conv_mfma256_lattice(const ConvKArgs& a, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s);
 
 static int device_cu_count() {
     static int n = 0;
@@ -721,6 +724,18 @@ bool conv_mfma256_uses_halo(const ConvKArgs& a, int groups) {
     return a.ksteps >= 4 && !a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht);
 }
 
+// Whether launch_conv_mfma256 sends this conv to the row-sub-lattice halo kernel (dilated 3x3 layers, conv_mfma256_lattice.hip).
+bool conv_mfma256_uses_lattice(const ConvKArgs& a, int groups) {
+#ifdef C256_T_NOLATTICE
+    return false;
+#endif
+    int nbias = 0;
+    for (int g = 0; g < groups; ++g) nbias = a.g[g].bias_off + a.cout > nbias ? a.g[g].bias_off + a.cout : nbias;
+    nbias = (nbias + 255) / 256 * 256;
+    const unsigned long long in_bytes = (unsigned long long)(a.M / a.HmWm) * a.in_Hp * a.in_Wp * a.in_C * 2ull;
+    return a.ksteps >= 4 && nbias <= 1024 && in_bytes < (1ull << 32) && conv_mfma256_lattice_dilation(a, groups) != 0;
+}
+
 hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* tile_ctr, float* stat_out, hipStream_t s) {
     dim3 block(512, 1, 1);
     int nbias = 0;
@@ -737,6 +752,8 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
         if (!a.res && (a.ntaps == 9 || a.ntaps == 4) && nbias <= 1024 && conv_mfma256_halo_supported(a, groups, &ht))
             return launch_conv_mfma256_halo(a, ht, groups, nbias, device_cu_count(), tile_ctr, stat_out, s);
         if (stat_out) return hipErrorInvalidValue;   // only the halo kernel writes softmax partials
+        // (-DC256_T_NOLATTICE, same-box A/B only: the dilated head conv on the generic persistent form)
+        if (conv_mfma256_uses_lattice(a, groups)) return launch_conv_mfma256_lattice(a, groups, nbias, device_cu_count(), tile_ctr, s);
         const int chunk = (a.MT + 7) / 8;
         int per_xcd = device_cu_count() / 8;
         if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
         xs_src = xb + ch * 128;
         xs_dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(WRING_ELEMS + hp * HALO_ELEMS + wave * 34 * 8) * 2u);
     };
+    // (Round 6, same box: the row slots that only repeat a staged row - taps 5 .. 8 with nine taps - cut down to ONE 16-byte piece
+    // through the lane mask, 35 KB less staging per chunk: heads.conv_d1 and the transposed convs unchanged within +-0.5 %.)
     auto xs_issue = [&](uint32_t roff) { DMA16_SBASE_LANES(roff, xs_src, xs_dst, xlanes); };
     auto xs_move = [&](bool down) {
         xs_src += down ? pitch_b : -pitch_b;

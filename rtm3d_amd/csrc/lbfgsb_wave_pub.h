@@ -73,6 +73,18 @@ __device__ static inline double lbw_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// A wave-uniform double (every lane computed the same bits from LDS broadcasts) handed to the compiler AS uniform: it may then live
+// in an SGPR pair - or, under pressure, in two lanes of a spill VGPR (v_writelane / v_readlane: a few cycles) - instead of two
+// VGPRs of every lane.  The loop-carried scalars of lbw_minimize (f, theta, the camera constants) are live across formk / subsm, whose
+// unrolled factorisations want every vector register: at the 168-register budget of twelve waves per workgroup they were the values
+// the allocator sent to scratch memory (a global-memory round trip inside a latency chain).  Same bits in, same bits out.
+__device__ static inline double lbw_uni(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+
 // f (returned, identical in every lane) and g (-> w->g) at w->x.
 __device__ static inline double lbw_fg(LbWaveMem* w, const LbWaveK& K, int lane) {
     const int c = lane >> 3, i = lane & 7;
@@ -230,24 +242,35 @@ __device__ static inline int lbw_trsv_ut(const double* a, int lda, int n, double
     WSYNC();
     return 0;
 }
-// U x = b (column-oriented back substitution, same update order as the scalar version): lane i owns b[i] and ROW i of U
+// U x = b (column-oriented back substitution, same update order as the scalar version): lane i owns b[i] and ROW i of U.
+// The row is fetched in two halves - entries 10 .. 19 before the chain starts, entries 0 .. 9 once the first five steps have
+// retired theirs (their LDS latency then runs under steps 14 .. 10) - so that at most 15 + 10 entries are live at once: with all
+// twenty up front (40 registers beside the iteration's state) the allocator sent four of them to scratch memory at the
+// 168-register budget of twelve waves per workgroup, and reloaded each inside the dependent chain.
 __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double* b, double* bc, int lane) {
     (void)bc;
     const bool act = lane < n;
     const int row = act ? lane : 0;
-    double rv[LB_M2];
+    constexpr int H = LB_M2 / 2;
+    double rh[H], rl[H];
 #pragma unroll
-    for (int j = 0; j < LB_M2; ++j) rv[j] = a[(j < n ? j : 0) * lda + row];
+    for (int j = 0; j < H; ++j) rh[j] = a[((H + j) < n ? (H + j) : 0) * lda + row];
     const double dg = a[row * lda + row];
     double bk = act ? b[lane] : 0.0;
     if (__any(act && dg == 0.0)) return 1;
 #pragma unroll
     for (int j = LB_M2 - 1; j >= 0; --j) {
+        if (j == LB_M2 - 6) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < H; ++q) rl[q] = a[(q < n ? q : 0) * lda + row];
+            asm volatile("" ::: "memory");
+        }
         if (j < n) {
             const double mine = bk * dg;                     // own (reciprocal) diagonal entry: lane j's is x_j
             const double tmp = -lbw_bcast(mine, j);
             if (lane == j) bk = mine;
-            if (lane < j) bk += tmp * rv[j];
+            if (lane < j) bk += tmp * (j >= H ? rh[j - H] : rl[j]);
         }
     }
     if (act) b[lane] = bk;
@@ -536,7 +559,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
     WSYNC();
     const long long tstart_ = __builtin_readcyclecounter();
 #endif
-    f = lbw_fg(w, K, lane); nfgv = 1;
+    f = lbw_uni(lbw_fg(w, K, lane)); nfgv = 1;
     {   // non-finite key points: x0, fun = NaN / Inf, 0 iterations, own status (see lb_minimize)
         bool finite = lb_isfinite(f);
         for (int i = 0; i < n; ++i) finite = finite && lb_isfinite(w->g[i]);
@@ -590,7 +613,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
             if (lane < n) w->x[lane] = (stp == 1.0) ? w->z[lane] : stp * w->d[lane] + w->t[lane];
             WSYNC();
             if (iback >= maxls) { ls_fail = 1; break; }
-            f = lbw_fg(w, K, lane);
+            f = lbw_uni(lbw_fg(w, K, lane));
         }
         PTE(tl_, 2);
         if (info != 0 || ls_fail) {
@@ -626,6 +649,7 @@ __device__ static inline int lbw_minimize(LbWaveMem* w, const LbWaveK& K, double
         updatd = 1; iupdat += 1;
         PTB(tm_);
         lbw_matupd(w, &itail, iupdat, &col, &head, &theta, rr, dr, stp, dtd, lane);
+        theta = lbw_uni(theta);
         PTE(tm_, 3); PTB(tt_);
         if (lbw_formt(w, col, theta, lane) != 0) { col = 0; head = 1; theta = 1.0; iupdat = 0; updatd = 0; }
         PTE(tt_, 4);

@@ -324,7 +324,7 @@ extern "C" int rtm3d_op_conv(rtm3d_ctx* ctx, const rtm3d_conv_desc* d) {
         op.kind = OP_CONV_MFMA256; op.bn_tile = 256;
         stat_slot = d->softmax_stat_slot;
         if (ensure_tile_ctr(ctx)) return 1;
-        op.name = d->ntaps == 1 ? "conv1x1_mfma256" : (d->ntaps == 4 ? "deconv4x4_phase_mfma256" : "conv3x3_mfma256");
+        op.name = d->ntaps == 1 ? "conv1x1_mfma256" : (d->ntaps == 4 ? "deconv4x4_phase_mfma256" : (conv_mfma256_uses_lattice(a, d->groups) ? "conv3x3_mfma256_lattice" : "conv3x3_mfma256"));
     } else if (d->kernel == 5) {
         // 64 -> 64 channel 3x3 halo kernel with the filter bank in registers (conv64_halo.hip)
         if (d->out_nchw_f32) RT_FAIL("op_conv(conv64): NCHW output unsupported");

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 from rtm3d_amd import plan as plan_mod, _lib     # noqa: E402
 
 
-def _run(P, feeds, fetch, x_img=None):
+def _run(P, feeds, fetch, x_img=None, expect_kernel=None):
     R = plan_mod.RealizedPlan(P, 0)
+    if expect_kernel is not None:
+        assert expect_kernel in R.kernel_names(), R.kernel_names()
     for s, arr in feeds:
         arr = np.ascontiguousarray(arr, np.float32)
         _lib.check(R.lib.rtm3d_tensor_upload(R.ctx, R.tids[s.tid], s.coff, s.C, arr.ctypes.data_as(ctypes.c_void_p)))
@@ -122,6 +124,30 @@ def test_halo_conv256_vs_torch(shape):
     ref = torch.cat([F.conv2d(h(torch.from_numpy(x[:, g * cin:(g + 1) * cin])), h(torch.from_numpy(ws[g])), torch.from_numpy(bs[g]), 1, 1)
                      for g in range(G)], 1).relu()
     ref = h(ref).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
+# (1, 48, 32, 64, 256): one 64-channel chunk -> every K-tile stages rows of the NEXT tile; (2, 48, 64, 256, 512): four chunks, two channel
+# tiles; (40, 48, 32, 128, 256): 240 tiles, a workgroup runs several in a row and the row ring wraps across tiles; (1, 96, 320, 256, 1024):
+# one image of the head conv itself; (3, 96, 64, 192, 256): three chunks (the ring base returns to 0 only every eight chunks)
+@pytest.mark.parametrize('shape', [(1, 48, 32, 64, 256), (2, 48, 64, 256, 512), (40, 48, 32, 128, 256), (1, 96, 320, 256, 1024), (3, 96, 64, 192, 256)])
+def test_lattice_conv256_vs_torch(shape):
+    """3x3 DILATION-6 convs (the fused head conv, header.py:12-16) whose map is covered by tiles of 8 lattice rows x 32 columns take
+    the row-sub-lattice halo kernel (conv_mfma256_lattice.hip: a ring of 16 halo-row slots); other shapes stay on the generic
+    persistent kernel (the (1, 16, 20, ...) dilation-6 case of CONV_CASES)."""
+    B, H, W, cin, cout = shape
+    rng = np.random.default_rng(B * 1000 + cin + cout)
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt = P.tensor(H, W, cin + 64, 6)
+    xs = P.sub(xt, 64, cin)
+    yt = P.tensor(H, W, cout, 1)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    P.conv(xs, yt, w, b, dil=6, relu=True, name='t')
+    P.ops[-1]['variant'] = 2
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    (got,), _ = _run(P, [(xs, x)], [yt], expect_kernel='conv3x3_mfma256_lattice')
+    ref = h(F.conv2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), torch.from_numpy(b), 1, 6, 6).relu()).numpy()
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
 
 

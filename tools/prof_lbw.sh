@@ -3,7 +3,7 @@
 # on it.  Build HERE (no GPU needed):  bash tools/prof_lbw.sh build ; then  gpurun -- 'bash tools/prof_lbw.sh run'
 set -e
 cd $(dirname $0)/..
-for k in 1; do
+for k in 1 2 3; do
   D=$PWD/rtm3d_amd/_C/prof$k
   if [ "$1" = build ]; then
     mkdir -p $D/obj
