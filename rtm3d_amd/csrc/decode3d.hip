@@ -53,6 +53,22 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 // 1.65 / 14.18 / 15.16; 8 vs 4: 1.57 / 14.06 / 15.01 vs 1.52 / 14.05 / 15.01; 8 vs 2: 1.57 / 14.01 / 15.01 vs 1.53 / 14.04 / 15.06:
 // flat between 2 and 8, 8 kept.  (With the published subspace step - 178 VGPRs, 67 KB per 8 objects - 12 and 16 objects per
 // workgroup needed VGPR caps that spilled: 15.62 / 16.02 / 16.12 ms per step at 473 objects.)
+// Round 6, with the published form as the default (239 registers x 8 waves and 67 KB of LDS per workgroup: a CU that holds one takes
+// no workgroup of the next batch's conv kernels), pipelined bs=32 ms/step, interleaved on one box each:
+//   objects per workgroup 2 / 4 / 8 / 10 / 12 (12 spill-free at 168 registers after the register diet of lbfgsb_wave_pub.h):
+//     12.98 / 12.95 / 12.69 / 12.90 / 13.19 - 8 stays;
+//   a WORK QUEUE (G persistent workgroups whose waves draw the valid slots from a ticket counter; bit-identical results): the
+//     bench workload's 474 objects need 34 iterations on average, p99 82, max 207 (tools/gpu_solver_nit.py), so the 82 workgroups
+//     with work of this kernel hold their CUs for twice the work they do - but G = 8 / 16 / 24 / 32 / 48 / 64 / 96 / 400 ran
+//     13.1 / 12.95 / 12.85 / 12.83 / 12.85 / 12.93 / 12.95 / 13.11 against 12.70-12.77 for this kernel.  The kernel traces say why
+//     (tools/gpu_trace_variants.sh): what the decode costs the next forward is mostly the SECOND ROUND it forces on layers that
+//     run one round of 240 tiles on 256 CUs (DLA level 4: 65 -> 100-110 us per conv while more than two CUs of an XCD are held),
+//     and a queue starts its last objects late - at + 1.5 ms most of its workgroups still hold one running object and all eight
+//     level-4 convs pay, where this launch (everything starts at once) has 6 of 82 workgroups left by then and only the first
+//     three pay (the stem and level 2 beside the full 82: + 0.13 / + 0.10 ms);
+//   the valid slots packed densely into 60 full workgroups (wave t takes the t-th valid slot, prefix sums over the images by a
+//     wave scan) instead of 82 partly filled ones: 13.05-13.12 against 12.80-12.86.
+// None kept.
 #ifndef D3_WPB_DEFAULT
 #define D3_WPB_DEFAULT 8
 #endif
