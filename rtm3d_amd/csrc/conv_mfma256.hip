@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512) void conv_mfma256_kernel(const ConvKArgs a) {
 // XNT = 1: a 1x1 conv with one channel tile reads every input byte once - its pixel operand goes through a non-temporal DMA
 // (see conv_mfma.hip).  A template parameter, not a run-time flag: as a flag it cost the head convs 12 SGPRs and 20 B of scratch.
 template <int RES, int XNT>
-__global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr) {
+__global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const ConvKArgs a, const int groups, const int nbias, unsigned int* tile_ctr, const int one_list) {
     __shared__ __attribute__((aligned(16))) f16 lds[2 * BUF_ELEMS + HALF_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[CONV256_MAX_BIAS + 4];   // + two ticket words
 #ifdef C256_STAMPS
@@ -423,8 +423,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
 
     // tile list of this workgroup: same XCD-contiguous order the one-tile kernel gets from the
     // dispatcher, position v -> (group, pixel tile, channel tile)
-    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-    const int chunk = (a.MT + 7) >> 3;
+    // one_list (round 6; launches with no more tiles than CUs, e.g. DLA level 4: 240 tiles): ONE list and ONE counter for the whole
+    // launch, and one workgroup per CU whatever the tile count.  Such a launch is a single round, and with a list per XCD it stays
+    // one only while no XCD has more than (32 - its tiles) CUs held by another stream's workgroups - the previous batch's 3D decode
+    // holds a few CUs for milliseconds, and every level-4 conv that met three of them on one XCD paid a second round (65 -> 100-110 us
+    // in the kernel trace, tools/gpu_trace_variants.sh).  With one list any 240 free CUs of the chip make it one round; what the
+    // per-XCD lists buy - neighbouring tiles through one L2 - matters for launches that stream many tiles per CU, not for these.
+    const int xcd = one_list ? 0 : blockIdx.x & 7, per_xcd = one_list ? gridDim.x : gridDim.x >> 3;
+    const int chunk = one_list ? a.MT : (a.MT + 7) >> 3;
     int mt_here = a.MT - xcd * chunk;
     mt_here = mt_here < 0 ? 0 : (mt_here > chunk ? chunk : mt_here);
     const int jbs = mt_here * a.NT;
@@ -437,16 +443,17 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     const int last_draw = vtotal + per_xcd - 1;
     // Tickets are drawn two tiles ahead: slot (i & 1) of lds_ticket holds tile i's, and is refilled with
     // tile i+2's while tile i runs.
+    // The FIRST ticket now, the second one behind the prologue's wait (round 6): a launch with about as many tiles as workgroups
+    // is one round only if every workgroup's first draw comes before anybody's second - drawn back to back, the workgroups that
+    // start a microsecond early take two tiles each and the late ones find the list empty (seen as 0.108 instead of 0.071 ms on
+    // a level-4 conv).  The prologue's operands take 2-3 us to land: by then every workgroup that is going to start has drawn.
     if (tid == 0) {
         const int t0 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        int t1 = t0;
-        if (t0 < vtotal) t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        if (t0 == last_draw || t1 == last_draw) tile_ctr[xcd] = 0u;
-        lds_ticket[0] = t0; lds_ticket[1] = t1;
+        if (t0 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[0] = t0;
     }
     __syncthreads();
     const int v = __builtin_amdgcn_readfirstlane(lds_ticket[0]);
-    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (v >= vtotal) return;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
@@ -558,7 +565,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_persistent_kernel(const Conv
     stage(SLOT_WB, 1, 1, 0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #endif
+    if (tid == 0) {                                       // the second ticket (see above); published by the barrier below
+        const int t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        if (t1 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[1] = t1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
     f16x8 xf[4][2], wa[2][2], wb[2][2];
@@ -754,14 +768,18 @@ hipError_t launch_conv_mfma256(const ConvKArgs& a, int groups, unsigned int* til
         if (stat_out) return hipErrorInvalidValue;   // only the halo kernel writes softmax partials
         // (-DC256_T_NOLATTICE, same-box A/B only: the dilated head conv on the generic persistent form)
         if (conv_mfma256_uses_lattice(a, groups)) return launch_conv_mfma256_lattice(a, groups, nbias, device_cu_count(), tile_ctr, s);
-        const int chunk = (a.MT + 7) / 8;
-        int per_xcd = device_cu_count() / 8;
-        if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+        // One workgroup per CU even when there are fewer tiles (level 4: 240): with exactly as many workgroups as tiles ONE CU held
+        // by another stream's workgroup costs the launch a second round; the spare workgroups find the list empty and leave.
+        // Launches of at most one round take one list for the whole chip (see the kernel).  Round 6, same box, pipelined bs=32
+        // ms/step (the previous batch's 3D decode beside every forward): grid clamped to the tile count, lists per XCD 12.82-12.87 |
+        // + second ticket behind the prologue 12.79-12.86 | + 256 workgroups 12.79-12.84 | + ONE list 12.60-12.63.
+        const int per_xcd = device_cu_count() / 8;
+        const int one_list = (long long)a.MT * a.NT * groups <= device_cu_count() ? 1 : 0;
         dim3 grid(per_xcd * 8, 1, 1);
         const bool x_once = !a.res && a.ntaps == 1 && a.NT == 1 && a.in_stride == 1;
-        if (a.res) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<1, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr);
-        else if (x_once) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 1>), grid, block, 0, s, a, groups, nbias, tile_ctr);
-        else hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr);
+        if (a.res) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<1, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr, one_list);
+        else if (x_once) hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 1>), grid, block, 0, s, a, groups, nbias, tile_ctr, one_list);
+        else hipLaunchKernelGGL((conv_mfma256_persistent_kernel<0, 0>), grid, block, 0, s, a, groups, nbias, tile_ctr, one_list);
         return hipGetLastError();
     }
     if (stat_out) return hipErrorInvalidValue;       // only the halo kernel writes softmax partials

@@ -56,7 +56,7 @@ struct HaloTaps { unsigned long long taps[RT_MAX_GROUPS]; };
 
 template <int STATS, int NTAP>          // NTAP: 9 (3 x 3 layers) or 4 (one sub-pixel phase of a 4 x 4 / stride-2 transposed conv)
 __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs a, const HaloTaps ht, const int groups, const int nbias,
-                                                                unsigned int* tile_ctr, float* stat_out) {
+                                                                unsigned int* tile_ctr, float* stat_out, const int one_list) {
     __shared__ __attribute__((aligned(128))) f16 lds[WRING_ELEMS + 2 * HALO_ELEMS];
     __shared__ __attribute__((aligned(16))) float lds_bias[HALO_MAX_BIAS + 4];     // + two ticket words
 #ifdef C256_STAMPS
@@ -71,24 +71,23 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     for (int i = tid; i < nbias; i += 512) lds_bias[i] = a.bias[i];
 
     // tile list (as conv_mfma256_persistent_kernel): position v -> (group, pixel tile, channel tile)
-    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-    const int chunk = (a.MT + 7) >> 3;
+    // (one_list: a launch of at most one round draws from ONE list with one workgroup per CU - conv_mfma256_persistent_kernel)
+    const int xcd = one_list ? 0 : blockIdx.x & 7, per_xcd = one_list ? gridDim.x : gridDim.x >> 3;
+    const int chunk = one_list ? a.MT : (a.MT + 7) >> 3;
     int mt_here = a.MT - xcd * chunk;
     mt_here = mt_here < 0 ? 0 : (mt_here > chunk ? chunk : mt_here);
     const int jbs = mt_here * a.NT;
     const int vtotal = jbs * groups;
     int* const lds_ticket = (int*)(lds_bias + HALO_MAX_BIAS);
     const int last_draw = vtotal + per_xcd - 1;
+    // (the second ticket is drawn behind the prologue's wait: conv_mfma256_persistent_kernel)
     if (tid == 0) {
         const int t0 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        int t1 = t0;
-        if (t0 < vtotal) t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        if (t0 == last_draw || t1 == last_draw) tile_ctr[xcd] = 0u;
-        lds_ticket[0] = t0; lds_ticket[1] = t1;
+        if (t0 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[0] = t0;
     }
     __syncthreads();
     const int v = __builtin_amdgcn_readfirstlane(lds_ticket[0]);
-    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (v >= vtotal) return;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
@@ -198,7 +197,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_halo_kernel(const ConvKArgs 
     stage_w(0, wb_c + (size_t)CPT * (256 * 64), 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
     stage_w(1, wb_c + (size_t)CPT * (256 * 64), 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        const int t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        if (t1 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[1] = t1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
     f16x8 xf[4][2], wa[2][2], wb[2][2];
@@ -532,20 +538,19 @@ bool conv_mfma256_halo_supported(const ConvKArgs& a, int groups, HaloTaps* ht) {
 }
 
 hipError_t launch_conv_mfma256_halo(const ConvKArgs& a, const HaloTaps& ht, int groups, int nbias, int cu_count, unsigned int* tile_ctr, float* stat_out, hipStream_t s) {
-    const int chunk = (a.MT + 7) / 8;
-    int per_xcd = cu_count / 8;
-    if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+    const int per_xcd = cu_count / 8;
+    const int one_list = (long long)a.MT * a.NT * groups <= cu_count ? 1 : 0;      // (launch_conv_mfma256)
 #ifdef HALO_T_NOSTATS
     stat_out = nullptr;     // (timing only: what do the softmax partials cost their producers?  round 5, same box: 0.504 / 0.510 / 0.513 ms
                             //  with them, 0.467 / 0.475 / 0.486 without = 2.3 us of a 31 us tile, 128 v_exp_f32 per lane)
 #endif
     const dim3 grid(per_xcd * 8, 1, 1), block(512, 1, 1);
     if (a.ntaps == 9) {
-        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
-        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out, one_list);
+        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 9>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out, one_list);
     } else if (a.ntaps == 4) {
-        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
-        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out);
+        if (stat_out) hipLaunchKernelGGL((conv_mfma256_halo_kernel<1, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out, one_list);
+        else hipLaunchKernelGGL((conv_mfma256_halo_kernel<0, 4>), grid, block, 0, s, a, ht, groups, nbias, tile_ctr, stat_out, one_list);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -59,16 +59,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_lattice_kernel(const ConvKAr
     const int vtotal = jbs * groups;
     int* const lds_ticket = (int*)(lds_bias + LT_MAX_BIAS);
     const int last_draw = vtotal + per_xcd - 1;
+    // (the second ticket is drawn behind the prologue's wait: conv_mfma256_persistent_kernel)
     if (tid == 0) {
         const int t0 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        int t1 = t0;
-        if (t0 < vtotal) t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
-        if (t0 == last_draw || t1 == last_draw) tile_ctr[xcd] = 0u;
-        lds_ticket[0] = t0; lds_ticket[1] = t1;
+        if (t0 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[0] = t0;
     }
     __syncthreads();
     const int v = __builtin_amdgcn_readfirstlane(lds_ticket[0]);
-    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (v >= vtotal) return;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LDS_AS f16*)lds;
@@ -156,7 +154,14 @@ __global__ __launch_bounds__(512) void conv_mfma256_lattice_kernel(const ConvKAr
     stage_w(0, wb_c + (size_t)CPT * (256 * 64), 1);                  // K-tile 1 = (chunk 0, tap 1): packed index 1 * CPT + 0
     stage_w(1, wb_c + (size_t)CPT * (256 * 64), 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        const int t1 = (int)atomicAdd(&tile_ctr[xcd], 1u);
+        if (t1 == last_draw) tile_ctr[xcd] = 0u;
+        lds_ticket[1] = t1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int vnext = __builtin_amdgcn_readfirstlane(lds_ticket[1]);
     if (wave >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
     f16x8 xf[4][2], wa[2][2], wb[2][2];
@@ -385,9 +390,7 @@ int conv_mfma256_lattice_dilation(const ConvKArgs& a, int groups) {
 }
 
 hipError_t launch_conv_mfma256_lattice(const ConvKArgs& a, int groups, int nbias, int cu_count, unsigned int* tile_ctr, hipStream_t s) {
-    const int chunk = (a.MT + 7) / 8;
-    int per_xcd = cu_count / 8;
-    if (per_xcd > chunk * a.NT * groups) per_xcd = chunk * a.NT * groups;
+    const int per_xcd = cu_count / 8;          // one workgroup per CU whatever the tile count (launch_conv_mfma256)
     const dim3 grid(per_xcd * 8, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL((conv_mfma256_lattice_kernel<6>), grid, block, 0, s, a, groups, nbias, tile_ctr);
     return hipGetLastError();
