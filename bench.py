@@ -777,7 +777,7 @@ def main():
         # (the file says when and on which tree it was collected: a stale figure shows in the line - `traffic_source`,
         # `traffic_age_days`, and `traffic_tree` against `tree` = the kernels' source hash of THIS run)
         traffic, traffic_src, traffic_age, traffic_tree = None, None, None, None
-        for prof in ('r05_pmc_heads.json', 'r04_pmc_heads.json', 'r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
+        for prof in ('r06_pmc_heads.json', 'r05_pmc_heads.json', 'r04_pmc_heads.json', 'r03_pmc_heads.json', 'r02_pmc_heads.json', 'r01_pmc_heads.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', prof)) as f:
                     pmc = json.load(f)

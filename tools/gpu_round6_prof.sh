@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU profiling session (round 5): per-op table, rocprofv3 kernel trace + stats (CSV), three PMC passes, and the head convs on
+# GPU profiling session (round 6): per-op table, rocprofv3 kernel trace + stats (CSV), three PMC passes, and the head convs on
 # all-zero weights (what the same kernels do when the MFMA operands carry no energy): per-op table + GRBM_GUI_ACTIVE with
 # kernel durations of the same run -> effective clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS give-back)
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5_prof
+O=$R/gpurun_out/r6_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # provenance of everything collected here (tools/pmc_heads.py copies it into the summary; bench.py prints it with `roofline.traffic`)

@@ -8,7 +8,7 @@ import csv
 import glob
 import sys
 
-KERNEL = ('conv_mfma256_persistent_kernel', 'conv_mfma256_halo_kernel')
+KERNEL = ('conv_mfma256_persistent_kernel', 'conv_mfma256_halo_kernel', 'conv_mfma256_lattice_kernel')
 
 
 def perop(path):

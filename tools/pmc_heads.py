@@ -4,7 +4,7 @@ usage: pmc_heads.py <per-op table of bench.py --per-op> <pmc dir> [<pmc dir> ...
 import csv, sys, glob, json, collections
 perop, dirs = sys.argv[1], sys.argv[2:]
 ops = [l.split()[0] for l in open(perop) if 'mfma256' in l and not l.startswith('{')]
-KERNEL = ('conv_mfma256_persistent_kernel', 'conv_mfma256_halo_kernel')
+KERNEL = ('conv_mfma256_persistent_kernel', 'conv_mfma256_halo_kernel', 'conv_mfma256_lattice_kernel')
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
