@@ -1,10 +1,10 @@
 // Wave-cooperative L-BFGS-B with the PUBLISHED subspace step (formk / subsm / formt: the form SciPy's L-BFGS-B 3.0 runs, and the
 // form utils/model_utils.py:295-296 therefore runs in the reference): ONE 64-lane wavefront solves ONE object.
 //
-// This is the round-2 product solver (git fdc3025, before the search direction moved to the two-loop recursion of
-// lbfgsb_wave.h), brought back in round 5 so that the SciPy-faithful form can serve the product path
-// (rtm3d_decode3d_slots form = 1): same algorithm and the same fp64 arithmetic in the same order as lb_minimize(direct = 0),
-// bit-identical to it (tests/test_gpu_parity.py::test_decode3d_large_fixture[slots_published]).
+// History: the round-2 product solver (git fdc3025), replaced as the default by the two-loop direction of lbfgsb_wave.h at the end of
+// round 2, back on the product path in round 5 (rtm3d_decode3d_slots form = 1) and THE DEFAULT of every entry since round 6
+// (rtm3d_decode3d / rtm3d_decode3d_slots form = RTM3D_SOLVER_PUBLISHED): same algorithm and the same fp64 arithmetic in the same
+// order as lb_minimize(direct = 0), bit-identical to it (tests/test_gpu_parity.py::test_decode3d_large_fixture, ..._wave_kernel_equals_scalar_kernel).
 //   - all limited-memory matrices live in LDS (8.4 KB per object) instead of per-lane scratch,
 //   - independent matrix entries / right-hand sides / vector components are spread over lanes
 //     (formk rows and columns, the 55 entries of T and of the (2,2) block, the col right-hand sides
@@ -13,8 +13,10 @@
 //     partial sums updated in pivot order (identical rounding to the dot-product form),
 //   - scalar control (line search state, convergence tests) is computed redundantly by every lane
 //     from LDS broadcasts, so control flow stays wave-uniform without any cross-lane traffic.
-// Costs against the direct form (round-2 measurements): 35.7k instead of 14.7k cycles per iteration, 178 instead of 116 VGPRs,
-// 67 KB instead of 20 KB of LDS per 8-object workgroup; +0.16 ms per pipelined bs=32 step at ~470 objects.
+// Costs (round 6, tools/prof_lbw.sh on the 64 golden objects): 35.5k cycles per iteration - formk 17.1k (potrf2 of WN(1,1) + T 4.3k, the
+// ten right-hand-side solves 3.0k, potrf of the (2,2) block 4.6k, WN from WN1 1.7k), subsm 7.1k (two 20-step substitutions 2.2k + 2.1k),
+// line search 5.8k, matupd 1.6k, formt 1.5k - against 14.7k for the direct form; 239 VGPRs (spill-free down to 168: lbw_uni, lbw_trsv_un),
+// 67 KB of LDS per 8-object workgroup; + 0.33 ms per pipelined bs=32 step at ~470 objects (12.69 against 12.36 ms).
 // Everything sits in namespace lbw_pub: the type and function names are those of lbfgsb_wave.h.
 #pragma once
 #include "lbfgsb.h"

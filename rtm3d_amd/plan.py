@@ -498,7 +498,7 @@ def choose_variant(cin, cout, M, groups, out_nchw, ntaps=9, stride=1):
         # full rounds (512): a single nearly full round - DLA level4, 240 tiles - was 12 % faster per launch on this kernel but
         # 0.1-0.5 ms SLOWER per pipelined step, because the previous batch's 3D decode (178 VGPRs x 8 waves and 67 KB of LDS per
         # workgroup, resident for ~3 ms) held ~60 CUs that a 160 KB workgroup cannot share.  With the direct-form solver
-        # (116 VGPRs, 20 KB, ~1 ms beside the forward) the same switch gains 0.08-0.13 ms per step (tools/gpu_v2tiles_ab.sh:
+        # (116 VGPRs, 20 KB, ~1 ms beside the forward) the same switch gains 0.08-0.13 ms per step (round-3 same-box A/B:
         # 14.03 / 14.09 / 14.08 -> 13.95 / 13.96 / 14.01 ms).
         # (the 1x1 projections / roots and the stride-2 entry conv of level4 measured 0.023 / 0.052 ms on this kernel against
         # 0.019 / 0.049 on the 128-pixel one: the single-round bar is for stride-1 layers with at least 8 K-steps)

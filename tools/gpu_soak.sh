@@ -15,3 +15,7 @@ run --batch 1 --steps 10000 --warmup 50 --sparse-heads
 run --backbone RESNET-18 --batch 8 --steps 3000 --warmup 20 --sparse-heads
 run --steps 500 --warmup 10 --heat-bias 2 --sparse-heads
 run --steps 500 --warmup 10 --from-uint8 step --sparse-heads
+# round 6: the opt-in direct solver form next to the default (published) one
+run --steps 1000 --warmup 10 --solver-form direct
+run --batch 1 --steps 10000 --warmup 50 --solver-form direct
+run --steps 500 --warmup 10 --heat-bias 2 --solver-form direct
