@@ -331,6 +331,11 @@ __global__ __launch_bounds__(512) void conv_mfma256_lattice_kernel(const ConvKAr
         if (wave < 4) __builtin_amdgcn_s_barrier();
 
         // ---- epilogue: 16 independent 16-byte stores, no loads from global memory
+        // (Round 6, same box: the epilogue of the three accumulator quadrants that are complete after phases 1-3 of the LAST K-tile
+        // issued in that K-tile's load segments - ~45 vector instructions + 4 stores each, behind the segment's DMA, counted waits
+        // 6 | 10 | 14 | 18 and 22 | 18 | 14 | 6 in the next tile's first K-tile - so that three quarters of the stores drain under
+        // the tile's own MFMAs: heads.conv_d6 3.367 / 3.367 / 3.386 against 3.386 / 3.385 / 3.373 ms.  Within the noise: at the power
+        // cap the tile boundary is not what this kernel waits for.  Removed.)
         {
             const ConvGroupArgs& g = a.g[gi_c];
             const int cbase = g.out_coff + nt_c * 256 + wc * 32 + so_ch;
