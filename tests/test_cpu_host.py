@@ -136,6 +136,26 @@ def test_library_exports_every_declared_symbol(built):
     assert int(subprocess.check_output([exe])) == ctypes.sizeof(_lib.ConvDesc)
 
 
+def test_abi9_solver_form_surface(built):
+    """Round 6 (ABI 9): the SciPy-faithful `published` form is what every facade entry passes unless told otherwise, both decode
+    entries carry the `form` argument in the header and in the binding (argument counts agree with the C prototypes), unknown forms
+    are refused on the host, and the retired side-lane replay is gone from the header, the binding and the library."""
+    from rtm3d_amd import model_utils
+    assert model_utils.DEFAULT_SOLVER_FORM == 'published' and model_utils.solver_form_id(None) == 1
+    assert model_utils.solver_form_id('direct') == 0 and model_utils.solver_form_id('published') == 1
+    with pytest.raises(ValueError, match='solver form'):
+        model_utils.solver_form_id('scipy')
+    hdr = open(os.path.join(REPO, 'include', 'rtm3d_hip.h')).read()
+    assert '#define RTM3D_ABI_VERSION 9' in hdr and '#define RTM3D_SOLVER_PUBLISHED 1' in hdr and '#define RTM3D_SOLVER_DIRECT 0' in hdr
+    for name in ('rtm3d_decode3d', 'rtm3d_decode3d_slots'):
+        proto = re.search(r'int %s\(([^;]*)\);' % name, hdr).group(1)
+        assert proto.rstrip().endswith('int form'), name
+        assert len(proto.split(',')) == len(_lib.SIGNATURES[name][1]), name
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for gone in ('rtm3d_op_schedule', 'rtm3d_ctx_set_lanes'):
+        assert gone not in hdr.replace('rtm3d_op_schedule / rtm3d_ctx_set_lanes', '') and gone not in _lib.SIGNATURES and not hasattr(lib, gone), gone
+
+
 def test_no_cpu_fallback():
     cfg = rtm3d_amd.kitti_config('DLA-34')
     m = rtm3d_amd.create_model(cfg)
