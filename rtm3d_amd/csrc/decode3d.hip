@@ -53,8 +53,9 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 // 1.65 / 14.18 / 15.16; 8 vs 4: 1.57 / 14.06 / 15.01 vs 1.52 / 14.05 / 15.01; 8 vs 2: 1.57 / 14.01 / 15.01 vs 1.53 / 14.04 / 15.06:
 // flat between 2 and 8, 8 kept.  (With the published subspace step - 178 VGPRs, 67 KB per 8 objects - 12 and 16 objects per
 // workgroup needed VGPR caps that spilled: 15.62 / 16.02 / 16.12 ms per step at 473 objects.)
-// Round 6, with the published form as the default (239 registers x 8 waves and 67 KB of LDS per workgroup: a CU that holds one takes
-// no workgroup of the next batch's conv kernels), pipelined bs=32 ms/step, interleaved on one box each:
+// Round 6, with the published form as the default (then 239 registers x 8 waves - 135 since its Cholesky factorisations run in
+// registers - and 67 KB of LDS per workgroup: a CU that holds one takes no workgroup of the next batch's persistent conv kernels),
+// pipelined bs=32 ms/step, interleaved on one box each (all measured with the 239-register kernel):
 //   objects per workgroup 2 / 4 / 8 / 10 / 12 (12 spill-free at 168 registers after the register diet of lbfgsb_wave_pub.h):
 //     12.98 / 12.95 / 12.69 / 12.90 / 13.19 - 8 stays;
 //   a WORK QUEUE (G persistent workgroups whose waves draw the valid slots from a ticket counter; bit-identical results): the

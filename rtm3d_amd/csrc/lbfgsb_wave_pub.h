@@ -13,10 +13,12 @@
 //     partial sums updated in pivot order (identical rounding to the dot-product form),
 //   - scalar control (line search state, convergence tests) is computed redundantly by every lane
 //     from LDS broadcasts, so control flow stays wave-uniform without any cross-lane traffic.
-// Costs (round 6, tools/prof_lbw.sh on the 64 golden objects): 35.5k cycles per iteration - formk 17.1k (potrf2 of WN(1,1) + T 4.3k, the
-// ten right-hand-side solves 3.0k, potrf of the (2,2) block 4.6k, WN from WN1 1.7k), subsm 7.1k (two 20-step substitutions 2.2k + 2.1k),
-// line search 5.8k, matupd 1.6k, formt 1.5k - against 14.7k for the direct form; 239 VGPRs (spill-free down to 168: lbw_uni, lbw_trsv_un),
-// 67 KB of LDS per 8-object workgroup; + 0.33 ms per pipelined bs=32 step at ~470 objects (12.69 against 12.36 ms).
+// Costs (round 6, tools/prof_lbw.sh on the 64 golden objects): 34.3k cycles per iteration - formk 15.4k (Cholesky of WN(1,1) + T 4.7k and of
+// the (2,2) block 2.5k, one entry per lane in registers: lbw_potrf_lanes; 4.3k + 4.6k through LDS before; the ten right-hand-side
+// solves 2.9k, WN from WN1 1.6k), subsm 7.2k (two 20-step substitutions 2.2k + 2.2k), line search 6.0k, matupd 1.6k, formt 1.5k -
+// against 14.7k for the direct form; 135 VGPRs (239 with the unrolled through-LDS factorisations), 67 KB of LDS per 8-object
+// workgroup; the bench batch's decode kernel alone 2.62 ms (2.93 before, 1.64 for the direct form); per pipelined bs=32 step at
+// ~470 objects + 0.33 ms over the direct form before this round's changes.
 // Everything sits in namespace lbw_pub: the type and function names are those of lbfgsb_wave.h.
 #pragma once
 #include "lbfgsb.h"
@@ -138,79 +140,60 @@ __device__ static inline double lbw_dot8(const double* a, const double* b) {
     return s;
 }
 
-// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block (n <= LB_M), in place; the diagonal of
-// the result holds 1 / u_jj (lb_potrf).
-// One template instance per pivot: the inner trip counts are compile-time constants, so all LDS
-// operands of a step are issued together (a rolled loop pays one LDS round trip per term).
-// Every sum still runs in index order.
-// (Measured alternative, not kept: columns and running dot sums in registers for the whole factorisation, row entries
-// by v_readlane - no LDS round trip per pivot, but the 45 broadcast-multiply-add updates of a 10 x 10 block sit in the
-// same in-order instruction stream as the pivot chain: +1.2k cycles per factorisation.)
-template <int J>
-__device__ static inline int lbw_potrf_step(double* a, int lda, int n, int lane) {
-    const int i = J + 1 + lane;
-    const bool act = i < n;
-    const int ic = act ? i : J;
-    double cj[J > 0 ? J : 1], ci[J > 0 ? J : 1];
+// Cholesky A = U'U (upper, column-major, leading dimension lda) of an n x n block (n <= LB_M), in place; the diagonal of the result
+// holds 1 / u_jj (lb_potrf) - of ONE block (b == nullptr) or of TWO independent blocks at once (WN's (1,1) block together with T:
+// formt's factorisation of T is only ever consulted for its positive-definiteness verdict - without bounds nothing calls bmv - and it
+// is the last thing an iteration does before the next formk, so it rides along there).  Returns 0, or 1 if `a` failed, or 2 if `b`
+// failed (the caller resets the limited-memory matrices in both cases, exactly as lb_minimize does after either failure).
+//
+// Round 6: ONE ENTRY PER LANE, in registers.  Lane e < 55 owns entry (row r, column c), r <= c, e = c (c + 1) / 2 + r, of each block,
+// and the running dot product sum_{k < r} u_kr u_kc that the dot-product form subtracts from it - accumulated term by term in k order
+// from 0.0, one term per pivot, so every value is rounded exactly as in lb_potrf (the scalar form) and in the round-2 form of this
+// function (one pivot per step through LDS: two LDS round trips, a dot product of length J and two wave fences per pivot, ~440
+// cycles).  Per pivot k here: the diagonal entry's a_kk - dot goes to every lane by v_readlane and every lane takes the reciprocal
+// square root of it (the same bits everywhere: no second broadcast); the lanes of row k scale their entries; the lanes below gather
+// u_kr and u_kc from the two row-k lanes above them with ds_bpermute (no memory behind it) and add one product to their dot.
+// The blocks are read from LDS once and written back once.
+template <bool TWO>
+__device__ static inline int lbw_potrf_lanes(double* a, int lda, double* b, int ldb, int n, int lane) {
+    const int e = lane < (LB_M * (LB_M + 1)) / 2 ? lane : (LB_M * (LB_M + 1)) / 2 - 1;
+    const int c = lbw_tri_col(e), r = e - c * (c + 1) / 2;
+    const bool act = lane < (LB_M * (LB_M + 1)) / 2 && c < n;
+    constexpr bool two = TWO;              // (a template parameter: as a run-time flag it put uniform branches between the two chains)
+    double va = act ? a[c * lda + r] : 0.0, vb = (act && two) ? b[c * ldb + r] : 0.0;
+    double da = 0.0, db = 0.0;
+    const int src_r = (r * (r + 1) / 2) << 2, src_c = (c * (c + 1) / 2) << 2;        // byte index of lane (0, r) / (0, c) for ds_bpermute
+    auto gather = [&](double v, int byte_idx) -> double {
+        const int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
+    // A pivot that is not positive ends the factorisation in the scalar form.  Here the verdict is collected and returned behind the
+    // loop (what the entries hold after a failed pivot is never read: every caller resets the matrices on a non-zero return): a
+    // return inside the loop would put a branch between the two blocks' reciprocal-square-root chains and run them one after the
+    // other (measured: 600 cycles per pivot for two blocks against 350 for one).
+    int fail_a = LB_M, fail_b = LB_M;                                    // first failing pivot of each block
 #pragma unroll
-    for (int k = 0; k < J; ++k) { cj[k] = a[J * lda + k]; ci[k] = a[ic * lda + k]; }
-    const double ajj0 = a[J * lda + J], aij = a[ic * lda + J];
-    double s = 0.0, dot = 0.0;
-#pragma unroll
-    for (int k = 0; k < J; ++k) { s += cj[k] * cj[k]; dot += cj[k] * ci[k]; }
-    const double ajj = ajj0 - s;
-    if (!(ajj > 0.0)) return J + 1;                     // uniform
-    const double rinv = lb_rsqrt(ajj);                  // the diagonal keeps 1 / u_jj (lb_potrf)
-    const double v = (aij - dot) * rinv;
-    WSYNC();                                            // everyone has read column J / a(J,J)
-    if (act) a[i * lda + J] = v;
-    if (lane == 0) a[J * lda + J] = rinv;
+    for (int k = 0; k < LB_M; ++k) {
+        if (k < n) {
+            const int dk = k * (k + 1) / 2 + k;                          // lane of the diagonal entry (k, k)
+            const double pa = va - da, pb = vb - db;                     // (row-k lanes: a_kc - dot; the diagonal lane: a_kk - s)
+            const double ajj_a = lbw_bcast(pa, dk), ajj_b = two ? lbw_bcast(pb, dk) : 1.0;
+            if (!(ajj_a > 0.0) && fail_a == LB_M) fail_a = k;            // uniform
+            if (!(ajj_b > 0.0) && fail_b == LB_M) fail_b = k;
+            const double ra = lb_rsqrt(ajj_a), rb = two ? lb_rsqrt(ajj_b) : 0.0;       // the diagonal keeps 1 / u_kk (lb_potrf)
+            const double ua = pa * ra, ub = pb * rb;
+            if (act && r == k) { va = c == k ? ra : ua; vb = c == k ? rb : ub; }
+            // lanes below row k: one more term of their dot products, u_kr * u_kc (row k's values sit in lanes src + k)
+            const double ukr_a = gather(ua, src_r + (k << 2)), ukc_a = gather(ua, src_c + (k << 2));
+            double ukr_b = 0.0, ukc_b = 0.0;
+            if (two) { ukr_b = gather(ub, src_r + (k << 2)); ukc_b = gather(ub, src_c + (k << 2)); }
+            if (act && r > k) { da += ukr_a * ukc_a; if (two) db += ukr_b * ukc_b; }
+        }
+    }
+    if (fail_a != LB_M || fail_b != LB_M) return fail_a <= fail_b ? 1 : 2;      // (at one pivot the first block's verdict comes first)
+    if (act) { a[c * lda + r] = va; if (two) b[c * ldb + r] = vb; }
     WSYNC();
-    return 0;
-}
-#define LBW_PSTEP(J) if (n <= J) return 0; { const int r_ = lbw_potrf_step<J>(a, lda, n, lane); if (r_) return r_; }
-__device__ static inline int lbw_potrf(double* a, int lda, int n, int lane) {
-    LBW_PSTEP(0) LBW_PSTEP(1) LBW_PSTEP(2) LBW_PSTEP(3) LBW_PSTEP(4)
-    LBW_PSTEP(5) LBW_PSTEP(6) LBW_PSTEP(7) LBW_PSTEP(8) LBW_PSTEP(9)
-    return 0;
-}
-
-// The same factorisation of TWO independent n x n blocks at once: lanes 0-15 own the columns of `a`, lanes 16-31 those of
-// `b` (same pivot index, same instruction stream - the second matrix is free in a SIMD that runs a serial chain on a
-// handful of lanes).  Used for WN's (1,1) block together with T: formt's factorisation of T is only ever consulted for
-// its positive-definiteness verdict (without bounds nothing calls bmv), and it is the last thing an iteration does before
-// the next formk, so it rides along there.  Returns 0, or 1 if `a` failed, or 2 if `b` failed (the caller resets the
-// limited-memory matrices in both cases, exactly as lb_minimize does after either failure).
-template <int J>
-__device__ static inline int lbw_potrf2_step(double* a, int lda, double* b, int ldb, int n, int lane) {
-    const bool hi = lane >= 16;
-    double* const m = hi ? b : a;
-    const int ld = hi ? ldb : lda;
-    const int i = J + 1 + (lane & 15);
-    const bool act = i < n && lane < 32;
-    const int ic = act ? i : J;
-    double cj[J > 0 ? J : 1], ci[J > 0 ? J : 1];
-#pragma unroll
-    for (int k = 0; k < J; ++k) { cj[k] = m[J * ld + k]; ci[k] = m[ic * ld + k]; }
-    const double ajj0 = m[J * ld + J], aij = m[ic * ld + J];
-    double s = 0.0, dot = 0.0;
-#pragma unroll
-    for (int k = 0; k < J; ++k) { s += cj[k] * cj[k]; dot += cj[k] * ci[k]; }
-    const double ajj = ajj0 - s;
-    const unsigned long long badm = __ballot(!(ajj > 0.0));      // lanes 0-15: `a`; all others hold `b`'s pivot
-    if (badm) return (badm & 0xffffull) ? 1 : 2;
-    const double rinv = lb_rsqrt(ajj);
-    const double v = (aij - dot) * rinv;
-    WSYNC();
-    if (act) m[i * ld + J] = v;
-    if ((lane & 15) == 0 && lane < 32) m[J * ld + J] = rinv;
-    WSYNC();
-    return 0;
-}
-#define LBW_P2STEP(J) if (n <= J) return 0; { const int r_ = lbw_potrf2_step<J>(a, lda, b, ldb, n, lane); if (r_) return r_; }
-__device__ static inline int lbw_potrf2(double* a, int lda, double* b, int ldb, int n, int lane) {
-    LBW_P2STEP(0) LBW_P2STEP(1) LBW_P2STEP(2) LBW_P2STEP(3) LBW_P2STEP(4)
-    LBW_P2STEP(5) LBW_P2STEP(6) LBW_P2STEP(7) LBW_P2STEP(8) LBW_P2STEP(9)
     return 0;
 }
 
@@ -387,7 +370,7 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
     WSYNC();
     PTE(f2_, 10); PTB(f3_);
     {   // WN (1,1) block, and T left unfactorised by lbw_formt at the end of the previous iteration
-        const int r2 = lbw_potrf2(w->wn, LB_M2, w->wt, LB_M, col, lane);
+        const int r2 = lbw_potrf_lanes<true>(w->wn, LB_M2, w->wt, LB_M, col, lane);
         if (r2 != 0) return r2 == 2 ? -3 : -1;
     }
     PTE(f3_, 11); PTB(f4_);
@@ -415,7 +398,7 @@ __device__ static inline int lbw_formk(LbWaveMem* w, int iupdat, double theta, i
         WSYNC();
     }
     PTE(f5_, 13); PTB(f6_);
-    if (lbw_potrf(&VWN_(col + 1, col + 1), LB_M2, col, lane) != 0) return -2;
+    if (lbw_potrf_lanes<false>(&VWN_(col + 1, col + 1), LB_M2, nullptr, 0, col, lane) != 0) return -2;
     PTE(f6_, 14);
     (void)col2;
     return 0;
@@ -542,7 +525,7 @@ __device__ static inline int lbw_formt(LbWaveMem* w, int col, double theta, int 
         }
     }
     WSYNC();
-    return 0;            // T's factorisation (a pass / fail verdict only) runs inside the next lbw_formk: lbw_potrf2
+    return 0;            // T's factorisation (a pass / fail verdict only) runs inside the next lbw_formk: lbw_potrf_lanes<true>
 }
 
 // Driver: identical control flow to lb_minimize (lbfgsb.h).  w->x holds x0 on entry, the result on exit.
