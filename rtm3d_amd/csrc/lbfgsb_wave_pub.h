@@ -267,6 +267,9 @@ __device__ static inline int lbw_trsv_un(const double* a, int lda, int n, double
 // soon as x_J exists its term goes into the running sums of all later rows (independent multiply-adds the SIMD pipelines),
 // so the dependent chain is 4 operations per step instead of 2 J + 2; each running sum still receives its terms in the
 // order k = 0, 1, ... from 0.0, i.e. the values are those of the row-oriented lb_trsv_ut.
+// (Round 6, same box: all 55 entries of U loaded up front - 55 broadcast reads in one batch instead of a row per step - 2.93k -> 2.27k
+// cycles for the solves, but 217 instead of 135 VGPRs for the kernel and 12.49 against 12.44 ms per pipelined step: at 135 registers
+// two stem waves fit on a SIMD beside the decode's two, at 217 none.  Not kept: the register count of this kernel is part of its cost.)
 // FULL: n == LB_M (every iteration once the memory is full: 16 of ~26) compiles without the per-index guards - the guarded
 // form keeps ~40 uniform predicates alive and spills SGPRs into VGPR lanes around every step.
 template <bool FULL>
