@@ -1,6 +1,6 @@
-// 3D box decode on device: the fp64 L-BFGS-B of lbfgsb.h, one wavefront per object (lbfgsb_wave.h, the product form: direct
-// two-loop search direction) or one lane per object (the cross-check kernels: the same direct form, bit-identical to the wave
-// kernel, and the published subspace form SciPy runs).
+// 3D box decode on device: the fp64 L-BFGS-B of lbfgsb.h, one wavefront per object - lbfgsb_wave_pub.h, the published subspace
+// step SciPy runs (the default since round 6), or lbfgsb_wave.h, the direct two-loop search direction (opt-in) - or one lane per
+// object (the cross-check kernels of the two forms, bit-identical to the wave kernels).
 // Replaces optim_decode_bbox3d (utils/model_utils.py:264-312) + scipy L-BFGS-B.
 // The work is latency-bound fp64 (a few hundred kFLOP per object, <= topk objects per image), so the
 // kernel only needs enough lanes in flight: 64-lane workgroups, objects spread over the CUs.
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
     status[i] = st;
 }
 
-// One wavefront per object (lbfgsb_wave.h): the production kernel.  A workgroup packs D3_WPB objects (8 waves, 20 KB of
-// LDS, 116 VGPRs): the ~15 objects of an image then sit on two CUs instead of fifteen, which matters when this kernel runs
+// One wavefront per object: the production kernel.  A workgroup packs D3_WPB objects (8 waves; direct form 20 KB of
+// LDS, 116 VGPRs; published form 67 KB, 135): the ~15 objects of an image then sit on two CUs instead of fifteen, which matters when this kernel runs
 // beside the forward pass of the next batch - a CU that holds these waves cannot take a workgroup of the persistent conv
 // kernels (160 KB of LDS) until they retire.  Objects per workgroup, pipelined ms/step at bs=1 serial / bs=32 with 473 /
 // with 3200 objects, pairs measured on one box each (profiles/r02_decode3d_load.json): 8 vs 16: 1.57 / 14.04 / 14.97 vs
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(64) void decode3d_kernel(int N, const int64_t* __re
 #ifndef D3_WPB_PUB
 #define D3_WPB_PUB 8
 #endif
-// FORM 0: the direct form (two-loop search direction, lbfgsb_wave.h) - the default of the product path;
-// FORM 1: the published subspace step (lbfgsb_wave_pub.h: what SciPy runs), selectable on the product path since round 5
-// (rtm3d_decode3d_slots form = 1): 8.4 KB of LDS per object, i.e. 67 KB per workgroup of eight.
+// FORM 0: the direct form (two-loop search direction, lbfgsb_wave.h), opt-in;
+// FORM 1: the published subspace step (lbfgsb_wave_pub.h: what SciPy runs), the default of every entry since round 6:
+// 8.4 KB of LDS per object, i.e. 67 KB per workgroup of eight.
 template <int D3_WPB, int FORM>
 __global__ __launch_bounds__(64 * D3_WPB) void decode3d_wave_kernel(int N, const int64_t* __restrict__ cls,
                                                            const float* __restrict__ verts, const double* __restrict__ K,
@@ -182,7 +182,7 @@ static int launch_scalar(int direct, void* stream, int N, const int64_t* d_cls, 
     return 0;
 }
 
-// the product's arithmetic (direct two-loop direction), one lane per object: bit-identical to rtm3d_decode3d
+// the direct form's arithmetic (two-loop direction), one lane per object: bit-identical to rtm3d_decode3d(form = RTM3D_SOLVER_DIRECT)
 extern "C" int rtm3d_decode3d_scalar(void* stream, int N, const int64_t* d_cls, const float* d_verts, const double* d_K,
                                      const double* d_dim_ref, int ncls, const double* d_ref_loc, double* d_x,
                                      double* d_fun, int32_t* d_nit, int32_t* d_status) {

@@ -16,8 +16,9 @@
 //
 // Two forms of the search direction (argument `direct` of lb_minimize):
 //   direct = 0  the published subspace step (formk / subsm, and formt as the positive-definiteness check): the form
-//               SciPy runs; kept as the cross-check (rtm3d_decode3d_reference_form, tests/host_lbfgsb.cpp);
-//   direct = 1  the PRODUCT form: the same vector  -B^-1 g  from the two-loop recursion over the same stored pairs
+//               SciPy runs and, since round 6, the product's DEFAULT (wave kernel: lbfgsb_wave_pub.h; this scalar form is its
+//               cross-check, rtm3d_decode3d_reference_form, tests/host_lbfgsb.cpp);
+//   direct = 1  the opt-in form: the same vector  -B^-1 g  from the two-loop recursion over the same stored pairs
 //               (lb_two_loop).  Without bounds the two are equal in exact arithmetic; in fp64 the iterates differ in the
 //               last bits, and now and then one form stops an iteration before the other.  Against the reference's SciPy
 //               results (keep / reject identical for both forms on every fixture; objects the reference rejects wander
@@ -25,8 +26,8 @@
 //               1536-object fixture (876 kept) direct 2.7e-5, published 1.3e-5; the bench's 111 planted boxes direct 1.6e-4
 //               (one object's yaw: 99.1 % within north_star's 1e-4), published 4.7e-7; three times 1500 synthetic cuboids on
 //               the host (profiles/r03_solver_forms_vs_scipy.txt): BOTH end further than 1e-4 from SciPy on 0.1-0.3 % of the
-//               kept objects.  The direct form costs about a third of the dependent fp64 operations per iteration; it is the
-//               default of the product path, the published one is selectable there (rtm3d_decode3d_slots form = 1).
+//               kept objects.  The direct form costs about 40 % of the dependent fp64 operations per iteration; it was the
+//               default of the product path in rounds 3-5 and is selectable since (form = RTM3D_SOLVER_DIRECT).
 //
 // The objective / gradient restate aimFun (utils/model_utils.py:155-177, cost=1e-4) and jac
 // (:206-234, cost=1e-6) in the reference's operation order.

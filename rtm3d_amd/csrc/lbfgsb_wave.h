@@ -1,5 +1,5 @@
-// Wave-cooperative form of lbfgsb.h in its PRODUCT form (lb_minimize with direct = 1): ONE 64-lane wavefront solves ONE
-// object.
+// Wave-cooperative form of lbfgsb.h in its DIRECT form (lb_minimize with direct = 1; the product's default in rounds 3-5, opt-in
+// since round 6: lbfgsb_wave_pub.h is the default): ONE 64-lane wavefront solves ONE object.
 //
 // Same algorithm and the same fp64 arithmetic in the same order as the scalar version - every individual sum runs
 // sequentially in index order - so the two are bit-identical (tests: rtm3d_decode3d vs rtm3d_decode3d_scalar):
