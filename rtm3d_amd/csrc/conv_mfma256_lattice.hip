@@ -30,6 +30,7 @@
 #define LT_RING 16                            // halo row slots
 #define LT_MAX_BIAS 1024
 
+
 #define LT_DMA16_SBASE_LANES RT_DMA16_SBASE_LANES
 #define LT_DMA16_SBASE RT_DMA16_SBASE
 #define LT_LDS_F16X8(byte_addr) (*(const LDS_AS f16x8*)(uintptr_t)(byte_addr))
@@ -93,11 +94,17 @@ __global__ __launch_bounds__(512) void conv_mfma256_lattice_kernel(const ConvKAr
     auto locate = [&](int vv, const char*& xb, const f16*& wb, int& gi, int& nt, int& n, int& y0, int& tx) {
         gi = vv / jbs;
         const int jb = vv - gi * jbs;
-        // (channel tiles of a pixel tile on adjacent tickets.  Round 6, same box: channel-tile-major over the XCD's list - one 1.2 MB
-        // weight set L2-resident per sweep, as the grouped head conv gets from its group-major order - or inside every image:
-        // 3.32-3.39 / 3.35-3.44 ms against 3.35-3.36: within the +-1 % of the box.)
-        const int q = jb / a.NT;
-        nt = jb - q * a.NT;
+        // Channel tiles in PAIRS: the two tiles of a pair on adjacent tickets, the XCD's whole pixel list per pair.  Round 6, fabric fetch
+        // per launch (FETCH_SIZE x 2, tools/gpu_pmc_fetch_variants.sh) / time: all four channel tiles adjacent (4.7 MB of weights per
+        // round through a 4 MB L2) 2.95 GB / 3.32-3.34 ms; pairs 2.41 GB / 3.31-3.39; one tile per sweep (pixel rows fetched four
+        // times) 3.06 GB / 3.32-3.45.  The time does not move (power cap); the pairs move least.
+        int q;
+        if (a.NT % 2 == 0) {
+            const int per = mt_here * 2;
+            const int grp = jb / per, rem = jb - grp * per;
+            q = rem >> 1;
+            nt = grp * 2 + (rem & 1);
+        } else { q = jb / a.NT; nt = jb - q * a.NT; }
         const int mt = xcd * chunk + q;
         n = mt / tpi;
         const int r = mt - n * tpi;
