@@ -151,6 +151,28 @@ def test_lattice_conv256_vs_torch(shape):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
 
 
+def test_lattice_kernel_is_not_taken_for_other_shapes():
+    """A dilation-6 conv whose map is NOT covered by tiles of 8 lattice rows x 32 columns (the KITTI letterbox 416 x 1280: H/4 = 104,
+    not a multiple of 48) stays on the generic persistent kernel - and is still right."""
+    B, H, W, cin, cout = 1, 104, 64, 64, 256
+    rng = np.random.default_rng(7)
+    P = plan_mod.Plan(B, H * 4, W * 4)
+    xt = P.tensor(H, W, cin, 6)
+    yt = P.tensor(H, W, cout, 1)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    P.conv(xt, yt, w, b, dil=6, relu=True, name='t')
+    P.ops[-1]['variant'] = 2
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    R = plan_mod.RealizedPlan(P, 0)
+    names = R.kernel_names()
+    R.close()
+    assert 'conv3x3_mfma256' in names and 'conv3x3_mfma256_lattice' not in names, names
+    (got,), _ = _run(P, [(xt, x)], [yt])
+    ref = h(F.conv2d(h(torch.from_numpy(x)), h(torch.from_numpy(w)), torch.from_numpy(b), 1, 6, 6).relu()).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ref).max()))
+
+
 def test_conv256_input_beyond_4gb():
     """The persistent 256 x 256 kernel addresses its pixel operand as an SGPR base + a 32-bit byte offset per lane (round 5): a conv
     whose input tensor is 4 GB or larger must not run on it (launch_conv_mfma256 sends it to the one-tile kernel, which carries
